@@ -1,0 +1,55 @@
+// Shared device helpers for the gfx950 kernels of libgts_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gts_hip.h"
+
+namespace gts {
+
+constexpr int kWave = 64;        // CDNA4 wavefront
+constexpr int kBlock = 256;      // 4 waves per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one L2).  Give each
+// XCD a contiguous span of tiles so that neighbouring rows of a supervoxel graph — whose
+// in-neighbours are nearby rows — are fetched through the same 4 MiB L2.  Bijective for
+// any grid size.  Speed only: correctness never depends on placement.
+__device__ __forceinline__ int xcd_contiguous_tile(int b, int nb) {
+  const int q = nb >> 3, r = nb & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+  float v[4];
+  __device__ __forceinline__ static Vec load(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    return Vec{{t.x, t.y, t.z, t.w}};
+  }
+  __device__ __forceinline__ void store(float* p) const {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <>
+struct Vec<1> {
+  float v[1];
+  __device__ __forceinline__ static Vec load(const float* p) { return Vec{{*p}}; }
+  __device__ __forceinline__ void store(float* p) const { *p = v[0]; }
+};
+
+inline int launch_status() {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? GTS_OK : static_cast<int>(e);
+}
+
+// smallest power of two >= x, capped at 64 (lanes that cooperate on one row)
+inline int lanes_per_row(int64_t vec_cols) {
+  int l = 1;
+  while (l < 64 && l < vec_cols) l <<= 1;
+  return l;
+}
+
+}  // namespace gts

@@ -1,0 +1,256 @@
+// K5-K8: GATConv attention (u_add_v + leaky_relu + edge softmax) fused with the weighted
+// neighbour aggregation, forward and backward, for gfx950.
+//
+// "Row" here is a (node, head) pair: row r = v*H + h owns the D-wide slice ft[v,h,:], so the
+// skeleton is the same lane-group row gather as gts_spmm.hip (D=256: one wave per
+// (node, head), 1 KiB per gathered slice).  The softmax statistics of a destination row are
+// a handful of scalars (in-degree ~6): every lane recomputes them from el/er (L1/L2
+// resident, [N,H] fp32) instead of exchanging them, which keeps the edge pass free of
+// LDS and barriers.  HBM-bound: no MFMA.
+#include "gts_rows.h"
+
+namespace gts {
+namespace {
+
+__device__ __forceinline__ float leaky(float x, float slope) { return x > 0.0f ? x : x * slope; }
+
+// sum over the LPR lanes that share a row (xor butterfly stays inside the aligned group)
+template <int LPR>
+__device__ __forceinline__ float group_sum(float x) {
+#pragma unroll
+  for (int m = LPR / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, kWave);
+  return x;
+}
+
+template <int LPR>
+__device__ __forceinline__ float group_max(float x) {
+#pragma unroll
+  for (int m = LPR / 2; m >= 1; m >>= 1) x = fmaxf(x, __shfl_xor(x, m, kWave));
+  return x;
+}
+
+// ------------------------------------------------------------------ forward
+template <int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
+    const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const float* __restrict__ ft, const float* __restrict__ el, const float* __restrict__ er,
+    float slope, float* __restrict__ out, float* __restrict__ attn, int n_rows, int heads,
+    int dim, int seq) {
+  const int gl = (threadIdx.x & (kWave - 1)) % LPR;
+  for (int s = 0; s < seq; ++s) {
+    const int r = owned_row<LPR>(s, seq, n_rows);
+    if (r < 0) continue;
+    const int v = r / heads, h = r - v * heads;
+    const int beg = indptr[v], end = indptr[v + 1];
+    const float er_v = er[r];
+    // pass 1: row maximum and softmax denominator; the group's lanes stride over the row's
+    // edges and combine with an xor butterfly (all lanes of a group share r: convergent)
+    float m = -INFINITY;
+    for (int k = beg + gl; k < end; k += LPR)
+      m = fmaxf(m, leaky(el[static_cast<size_t>(indices[k]) * heads + h] + er_v, slope));
+    m = group_max<LPR>(m);
+    float den = 0.0f;
+    for (int k = beg + gl; k < end; k += LPR)
+      den += expf(leaky(el[static_cast<size_t>(indices[k]) * heads + h] + er_v, slope) - m);
+    den = group_sum<LPR>(den);
+    // pass 2: weights + weighted gather
+    for (int c = gl * VEC; c < dim; c += LPR * VEC) {
+      float acc[VEC];
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) acc[t] = 0.0f;
+      for_chunks<LPR>(beg, end, [&](auto cnt_c, int k) {
+        constexpr int CNT = decltype(cnt_c)::value;
+        const Chunk<LPR, CNT> src(indices, k, end);
+        Vec<VEC> val[CNT];
+        float a[CNT];
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) {
+          const size_t urow = static_cast<size_t>(src[j]) * heads + h;
+          a[j] = el[urow];
+          val[j] = Vec<VEC>::load(ft + urow * dim + c);
+        }
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) {
+          if (src.valid(j)) {
+            a[j] = expf(leaky(a[j] + er_v, slope) - m) / den;
+            if (c == 0 && gl == 0) attn[static_cast<size_t>(k + j) * heads + h] = a[j];
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) acc[t] += a[j] * val[j].v[t];
+          }
+        }
+      });
+      Vec<VEC> o;
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) o.v[t] = acc[t];
+      o.store(out + static_cast<size_t>(r) * dim + c);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward, edge pass
+// ge[pos,h] first holds ga_k = <gout[v,h,:], ft[src_k,h,:]>, then is overwritten with
+// ge_k = a_k (ga_k - sum_j a_j ga_j) leaky'(.) by the same lane (lane 0 of the group).
+template <int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(
+    const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const float* __restrict__ ft, const float* __restrict__ el, const float* __restrict__ er,
+    const float* __restrict__ attn, const float* __restrict__ gout, float slope,
+    float* __restrict__ ge, float* __restrict__ ger, int n_rows, int heads, int dim, int seq) {
+  const int gl = (threadIdx.x & (kWave - 1)) % LPR;
+  for (int s = 0; s < seq; ++s) {
+    const int r = owned_row<LPR>(s, seq, n_rows);
+    // all lanes of a group share r, so the shuffles below are convergent per group;
+    // groups past the end still take part in the wave-wide shuffle with zeros.
+    const bool live = r >= 0;
+    const int v = live ? r / heads : 0, h = live ? r - v * heads : 0;
+    const int beg = live ? indptr[v] : 0, end = live ? indptr[v + 1] : 0;
+    int maxdeg = end - beg;
+    if constexpr (LPR != kWave) {
+#pragma unroll
+      for (int m = kWave / 2; m >= LPR; m >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, m, kWave));
+    }
+    float dot_sum = 0.0f;  // sum_j a_j ga_j
+    for (int i = 0; i < maxdeg; ++i) {
+      const int k = beg + i;
+      const bool on = k < end;
+      float part = 0.0f;
+      if (on) {
+        const size_t urow = static_cast<size_t>(indices[k]) * heads + h;
+        for (int c = gl * VEC; c < dim; c += LPR * VEC) {
+          const Vec<VEC> g = Vec<VEC>::load(gout + static_cast<size_t>(r) * dim + c);
+          const Vec<VEC> f = Vec<VEC>::load(ft + urow * dim + c);
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) part += g.v[t] * f.v[t];
+        }
+      }
+      const float ga = group_sum<LPR>(part);
+      if (on) {
+        const size_t pos = static_cast<size_t>(k) * heads + h;
+        dot_sum += attn[pos] * ga;
+        if (gl == 0) ge[pos] = ga;
+      }
+    }
+    if (live && gl == 0) {
+      const float er_v = er[r];
+      float ger_acc = 0.0f;
+      for (int k = beg; k < end; ++k) {
+        const size_t pos = static_cast<size_t>(k) * heads + h;
+        const float pre = el[static_cast<size_t>(indices[k]) * heads + h] + er_v;
+        const float g_e = attn[pos] * (ge[pos] - dot_sum) * (pre > 0.0f ? 1.0f : slope);
+        ge[pos] = g_e;
+        ger_acc += g_e;
+      }
+      ger[r] = ger_acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward, source pass
+template <int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void gat_bwd_src_kernel(
+    const int32_t* __restrict__ t_indptr, const int32_t* __restrict__ t_indices,
+    const int32_t* __restrict__ t_pos, const float* __restrict__ attn,
+    const float* __restrict__ ge, const float* __restrict__ gout, float* __restrict__ gft,
+    float* __restrict__ gel, int n_rows, int heads, int dim, int seq) {
+  const int gl = (threadIdx.x & (kWave - 1)) % LPR;
+  for (int s = 0; s < seq; ++s) {
+    const int r = owned_row<LPR>(s, seq, n_rows);
+    if (r < 0) continue;
+    const int u = r / heads, h = r - u * heads;
+    const int beg = t_indptr[u], end = t_indptr[u + 1];
+    if (gl == 0) {
+      float acc = 0.0f;
+      for (int k = beg; k < end; ++k) acc += ge[static_cast<size_t>(t_pos[k]) * heads + h];
+      gel[r] = acc;
+    }
+    for (int c = gl * VEC; c < dim; c += LPR * VEC) {
+      float acc[VEC];
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) acc[t] = 0.0f;
+      for_chunks<LPR>(beg, end, [&](auto cnt_c, int k) {
+        constexpr int CNT = decltype(cnt_c)::value;
+        const Chunk<LPR, CNT> dst(t_indices, k, end);
+        const Chunk<LPR, CNT> pos(t_pos, k, end);
+        Vec<VEC> val[CNT];
+        float a[CNT];
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) {
+          a[j] = attn[static_cast<size_t>(pos[j]) * heads + h];
+          val[j] = Vec<VEC>::load(gout + (static_cast<size_t>(dst[j]) * heads + h) * dim + c);
+        }
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) {
+          if (dst.valid(j)) {
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) acc[t] += a[j] * val[j].v[t];
+          }
+        }
+      });
+      Vec<VEC> o;
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) o.v[t] = acc[t];
+      o.store(gft + static_cast<size_t>(r) * dim + c);
+    }
+  }
+}
+
+inline bool bad_gat_shape(int64_t n, int64_t heads, int64_t dim) {
+  return n < 0 || heads <= 0 || dim <= 0 || heads > 4096 || dim >= (1LL << 24) ||
+         n * heads >= (1LL << 31);
+}
+
+}  // namespace
+}  // namespace gts
+
+extern "C" int32_t gts_gat_fwd_f32(const int32_t* indptr, const int32_t* indices,
+                                   const float* ft, const float* el, const float* er,
+                                   float negative_slope, float* out, float* attn, int64_t n,
+                                   int64_t heads, int64_t dim, void* stream) {
+  using namespace gts;
+  if (!indptr || !ft || !el || !er || !out || !attn) return GTS_ERR_NULL;
+  if (bad_gat_shape(n, heads, dim)) return GTS_ERR_SHAPE;
+  if (n == 0) return GTS_OK;
+  const Geometry g = make_geometry(n * heads, dim);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nr = static_cast<int>(n * heads), nh = static_cast<int>(heads), nd = static_cast<int>(dim);
+  GTS_DISPATCH_GEOM(g, {
+    gat_fwd_kernel<VEC, LPR><<<g.grid, kBlock, 0, st>>>(indptr, indices, ft, el, er, negative_slope, out, attn, nr, nh, nd, g.seq);
+  })
+  return launch_status();
+}
+
+extern "C" int32_t gts_gat_bwd_edge_f32(const int32_t* indptr, const int32_t* indices,
+                                        const float* ft, const float* el, const float* er,
+                                        const float* attn, const float* gout,
+                                        float negative_slope, float* ge, float* ger, int64_t n,
+                                        int64_t heads, int64_t dim, void* stream) {
+  using namespace gts;
+  if (!indptr || !ft || !el || !er || !attn || !gout || !ge || !ger) return GTS_ERR_NULL;
+  if (bad_gat_shape(n, heads, dim)) return GTS_ERR_SHAPE;
+  if (n == 0) return GTS_OK;
+  const Geometry g = make_geometry(n * heads, dim);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nr = static_cast<int>(n * heads), nh = static_cast<int>(heads), nd = static_cast<int>(dim);
+  GTS_DISPATCH_GEOM(g, {
+    gat_bwd_edge_kernel<VEC, LPR><<<g.grid, kBlock, 0, st>>>(indptr, indices, ft, el, er, attn, gout, negative_slope, ge, ger, nr, nh, nd, g.seq);
+  })
+  return launch_status();
+}
+
+extern "C" int32_t gts_gat_bwd_src_f32(const int32_t* t_indptr, const int32_t* t_indices,
+                                       const int32_t* t_pos, const float* attn,
+                                       const float* ge, const float* gout, float* gft,
+                                       float* gel, int64_t n, int64_t heads, int64_t dim,
+                                       void* stream) {
+  using namespace gts;
+  if (!t_indptr || !attn || !ge || !gout || !gft || !gel) return GTS_ERR_NULL;
+  if (bad_gat_shape(n, heads, dim)) return GTS_ERR_SHAPE;
+  if (n == 0) return GTS_OK;
+  const Geometry g = make_geometry(n * heads, dim);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nr = static_cast<int>(n * heads), nh = static_cast<int>(heads), nd = static_cast<int>(dim);
+  GTS_DISPATCH_GEOM(g, {
+    gat_bwd_src_kernel<VEC, LPR><<<g.grid, kBlock, 0, st>>>(t_indptr, t_indices, t_pos, attn, ge, gout, gft, gel, nr, nh, nd, g.seq);
+  })
+  return launch_status();
+}

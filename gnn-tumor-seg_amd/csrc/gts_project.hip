@@ -1,0 +1,170 @@
+// K12: node -> voxel projection ("scatter" in the reference's wording; a gather by supervoxel
+// id) + library-level entry points (ABI version, error strings).
+//
+// HBM-bound streaming: 2 B/voxel of int16 ids in, row_bytes/voxel out, the lookup table
+// (<= 32768 rows) stays in L2.  Lane l of a wave owns voxels base + j*64 + l, so every
+// store instruction writes 64 consecutive rows (1 KiB for fp32x4 logits) and the ids of a
+// 512-voxel wave tile arrive as ONE 16 B/lane load that is re-distributed through LDS.
+#include "gts_common.h"
+
+namespace gts {
+namespace {
+
+constexpr int kVoxPerLane = 8;                     // one 16-byte load of int16 ids
+constexpr int kVoxPerWave = kWave * kVoxPerLane;   // 512
+constexpr int kVoxPerBlock = kVoxPerWave * kWavesPerBlock;
+
+// Row index inside [table rows..., background]: numpy semantics of table_plus_bg[id]
+// for id in [-(n_rows+1), n_rows]; anything outside selects the background row.
+__device__ __forceinline__ int resolve_row(int id, int n_rows) {
+  const int r = id < 0 ? id + n_rows + 1 : id;
+  return (r < 0 || r > n_rows) ? n_rows : r;
+}
+
+// ids of this wave's tile -> per-lane registers, lane l gets voxels j*64 + l.
+__device__ __forceinline__ void load_tile_ids(const int16_t* __restrict__ svs, int64_t tile_base,
+                                              int64_t n_vox, int16_t* lds_wave,
+                                              int (&ids)[kVoxPerLane]) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t mine = tile_base + static_cast<int64_t>(lane) * kVoxPerLane;
+  if (mine + kVoxPerLane <= n_vox && (reinterpret_cast<uintptr_t>(svs + mine) & 15) == 0) {
+    *reinterpret_cast<uint4*>(lds_wave + lane * kVoxPerLane) =
+        *reinterpret_cast<const uint4*>(svs + mine);
+  } else {
+#pragma unroll
+    for (int j = 0; j < kVoxPerLane; ++j)
+      lds_wave[lane * kVoxPerLane + j] = mine + j < n_vox ? svs[mine + j] : int16_t(-1);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
+#pragma unroll
+  for (int j = 0; j < kVoxPerLane; ++j) ids[j] = lds_wave[j * kWave + lane];
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <typename RowT>
+__global__ __launch_bounds__(kBlock) void project_rows_kernel(
+    const int16_t* __restrict__ svs, const RowT* __restrict__ table,
+    const RowT* __restrict__ bg_row, RowT* __restrict__ out, int64_t n_vox, int n_rows) {
+  __shared__ int16_t lds[kVoxPerBlock];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  int16_t* lds_wave = lds + wave * kVoxPerWave;
+  const RowT bg = *bg_row;
+  const int64_t n_tiles = (n_vox + kVoxPerWave - 1) / kVoxPerWave;
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave; tile < n_tiles;
+       tile += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
+    const int64_t base = tile * kVoxPerWave;
+    int ids[kVoxPerLane];
+    load_tile_ids(svs, base, n_vox, lds_wave, ids);
+    RowT rows[kVoxPerLane];
+#pragma unroll
+    for (int j = 0; j < kVoxPerLane; ++j) {
+      const int r = resolve_row(ids[j], n_rows);
+      rows[j] = r == n_rows ? bg : table[r];
+    }
+#pragma unroll
+    for (int j = 0; j < kVoxPerLane; ++j) {
+      const int64_t i = base + j * kWave + lane;
+      if (i < n_vox) out[i] = rows[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void project_argmax_kernel(
+    const int16_t* __restrict__ svs, const float* __restrict__ logits,
+    const int16_t* __restrict__ relabel, int16_t* __restrict__ out, int64_t n_vox, int n_rows,
+    int n_classes) {
+  __shared__ int16_t lds[kVoxPerBlock];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  int16_t* lds_wave = lds + wave * kVoxPerWave;
+  const int64_t n_tiles = (n_vox + kVoxPerWave - 1) / kVoxPerWave;
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave; tile < n_tiles;
+       tile += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
+    const int64_t base = tile * kVoxPerWave;
+    int ids[kVoxPerLane];
+    load_tile_ids(svs, base, n_vox, lds_wave, ids);
+#pragma unroll
+    for (int j = 0; j < kVoxPerLane; ++j) {
+      const int r = resolve_row(ids[j], n_rows);
+      int label = 0;  // background voxels are healthy (graph_io.py:22-23)
+      if (r != n_rows) {
+        const float* row = logits + static_cast<size_t>(r) * n_classes;
+        float best = row[0];
+        for (int c = 1; c < n_classes; ++c) {
+          const float val = row[c];
+          if (best < val) best = val, label = c;  // first maximum, like torch.max(dim=1)
+        }
+      }
+      if (relabel != nullptr) label = relabel[label];
+      const int64_t i = base + j * kWave + lane;
+      if (i < n_vox) out[i] = static_cast<int16_t>(label);
+    }
+  }
+}
+
+inline unsigned stream_grid(int64_t n_vox) {
+  const int64_t blocks = (n_vox + kVoxPerBlock - 1) / kVoxPerBlock;
+  return static_cast<unsigned>(blocks < 4096 ? (blocks > 0 ? blocks : 1) : 4096);
+}
+
+}  // namespace
+}  // namespace gts
+
+extern "C" int32_t gts_abi_version(void) { return 1; }
+
+extern "C" const char* gts_error_string(int32_t code) {
+  switch (code) {
+    case GTS_OK: return "ok";
+    case GTS_ERR_NULL: return "gts: required pointer is NULL";
+    case GTS_ERR_SHAPE: return "gts: unsupported or inconsistent shape";
+    case GTS_ERR_ARGKIND: return "gts: unsupported arg_bytes/row_bytes/mode";
+    default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "gts: unknown error";
+  }
+}
+
+extern "C" int32_t gts_project_rows_i16(const int16_t* svs, const void* table,
+                                        const void* bg_row, void* out, int64_t n_vox,
+                                        int64_t n_rows, int32_t row_bytes, void* stream) {
+  using namespace gts;
+  if (!svs || !bg_row || !out || (n_rows > 0 && !table)) return GTS_ERR_NULL;
+  if (n_vox < 0 || n_rows < 0 || n_rows > 32768) return GTS_ERR_SHAPE;
+  if (n_vox == 0) return GTS_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned grid = stream_grid(n_vox);
+  const int nr = static_cast<int>(n_rows);
+  switch (row_bytes) {
+    case 4:
+      project_rows_kernel<uint32_t><<<grid, kBlock, 0, st>>>(
+          svs, static_cast<const uint32_t*>(table), static_cast<const uint32_t*>(bg_row),
+          static_cast<uint32_t*>(out), n_vox, nr);
+      break;
+    case 8:
+      project_rows_kernel<uint2><<<grid, kBlock, 0, st>>>(
+          svs, static_cast<const uint2*>(table), static_cast<const uint2*>(bg_row),
+          static_cast<uint2*>(out), n_vox, nr);
+      break;
+    case 16:
+      project_rows_kernel<uint4><<<grid, kBlock, 0, st>>>(
+          svs, static_cast<const uint4*>(table), static_cast<const uint4*>(bg_row),
+          static_cast<uint4*>(out), n_vox, nr);
+      break;
+    default:
+      return GTS_ERR_ARGKIND;
+  }
+  return launch_status();
+}
+
+extern "C" int32_t gts_project_argmax_i16(const int16_t* svs, const float* logits,
+                                          const int16_t* relabel, int16_t* out, int64_t n_vox,
+                                          int64_t n_rows, int64_t n_classes, void* stream) {
+  using namespace gts;
+  if (!svs || !out || (n_rows > 0 && !logits)) return GTS_ERR_NULL;
+  if (n_vox < 0 || n_rows < 0 || n_rows > 32768 || n_classes < 1 || n_classes > 1024)
+    return GTS_ERR_SHAPE;
+  if (n_vox == 0) return GTS_OK;
+  project_argmax_kernel<<<stream_grid(n_vox), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      svs, logits, relabel, out, n_vox, static_cast<int>(n_rows), static_cast<int>(n_classes));
+  return launch_status();
+}

@@ -1,0 +1,134 @@
+// Row-gather skeleton shared by the CSR kernels (spmm max/sum, GAT): lane groups, neighbour
+// chunks, launch geometry and the (VEC, LPR) dispatch.
+#pragma once
+#include <type_traits>
+
+#include "gts_common.h"
+
+namespace gts {
+
+constexpr int kUnroll = 8;
+
+// Row owned by this lane group for sequential step s; -1 when past the end.
+template <int LPR>
+__device__ __forceinline__ int owned_row(int s, int seq, int n_rows) {
+  constexpr int kRowsPerWave = kWave / LPR;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+  int v = ((tile * kWavesPerBlock + wave) * seq + s) * kRowsPerWave + lane / LPR;
+  if constexpr (LPR == kWave) v = __builtin_amdgcn_readfirstlane(v);
+  return v < n_rows ? v : -1;
+}
+
+// Neighbour chunks.  A row's in-edges are consumed in chunks of <= kUnroll so that all of a
+// chunk's row loads are in flight together.  Every chunk body is straight-line code:
+//  * LPR == 64 (row is wave-uniform): the exact count is a template parameter (switch on
+//    the remainder), lanes 0..CNT-1 fetch the chunk's indices with ONE vector load and each
+//    index is broadcast with v_readlane.  (Per-index s_load, or loads under `if (j < cnt)`,
+//    make hipcc wait vmcnt(0) in front of every row load.)
+//  * LPR < 64 (several rows per wave, divergent): always kUnroll entries, positions clamped
+//    to the row's last edge and the update guarded by `valid(j)`.
+template <int N>
+using IC = std::integral_constant<int, N>;
+
+template <int LPR, typename Body>
+__device__ __forceinline__ void for_chunks(int beg, int end, Body&& body) {
+  if constexpr (LPR == kWave) {
+    int k = beg;
+    for (; k + kUnroll <= end; k += kUnroll) body(IC<kUnroll>{}, k);
+    switch (end - k) {
+      case 1: body(IC<1>{}, k); break;
+      case 2: body(IC<2>{}, k); break;
+      case 3: body(IC<3>{}, k); break;
+      case 4: body(IC<4>{}, k); break;
+      case 5: body(IC<5>{}, k); break;
+      case 6: body(IC<6>{}, k); break;
+      case 7: body(IC<7>{}, k); break;
+      default: break;
+    }
+  } else {
+    for (int k = beg; k < end; k += kUnroll) body(IC<kUnroll>{}, k);
+  }
+}
+
+// entry j of the chunk starting at edge position k (of an int32 per-edge array)
+template <int LPR, int CNT>
+struct Chunk {
+  int reg;  // LPR == 64: lane l holds entry l
+  const int32_t* __restrict__ p;
+  int k, last;
+  __device__ __forceinline__ Chunk(const int32_t* __restrict__ arr, int k_, int end) : p(arr), k(k_), last(end - 1) {
+    if constexpr (LPR == kWave) {
+      const int lane = threadIdx.x & (kWave - 1);
+      reg = lane < CNT ? arr[k_ + lane] : 0;
+    } else {
+      reg = 0;
+    }
+  }
+  __device__ __forceinline__ int operator[](int j) const {
+    if constexpr (LPR == kWave) {
+      return __builtin_amdgcn_readlane(reg, j);
+    } else {
+      return p[min(k + j, last)];
+    }
+  }
+  __device__ __forceinline__ bool valid(int j) const {
+    if constexpr (LPR == kWave) return true;
+    return k + j <= last;
+  }
+};
+
+// rows each wave walks sequentially: enough tiles to fill 256 CUs several times over,
+// few enough that index prefetch amortises.
+inline int pick_seq(int64_t n_rows, int rows_per_wave_step) {
+  const int64_t steps = (n_rows + rows_per_wave_step - 1) / rows_per_wave_step;
+  // aim for >= 8192 waves (256 CUs x 32) before lengthening the per-wave walk
+  int seq = 1;
+  while (seq < 4 && steps / (seq * 2) >= 8192) seq *= 2;
+  return seq;
+}
+
+struct Geometry {
+  int vec, lpr, seq;
+  dim3 grid;
+};
+
+inline Geometry make_geometry(int64_t n_rows, int64_t n_feat) {
+  Geometry g;
+  g.vec = (n_feat % 4 == 0) ? 4 : 1;
+  g.lpr = lanes_per_row(n_feat / g.vec);
+  const int rows_per_step = kWave / g.lpr;
+  g.seq = pick_seq(n_rows, rows_per_step);
+  const int64_t rows_per_block = static_cast<int64_t>(rows_per_step) * g.seq * kWavesPerBlock;
+  g.grid = dim3(static_cast<unsigned>((n_rows + rows_per_block - 1) / rows_per_block));
+  return g;
+}
+
+inline bool bad_shape(int64_t n_rows, int64_t n_feat) {
+  return n_rows < 0 || n_feat <= 0 || n_rows >= (1LL << 31) || n_feat >= (1LL << 24);
+}
+
+}  // namespace gts
+
+// Dispatch on (VEC, LPR): LPR in {1,2,4,...,64} for VEC=4 and VEC=1.
+#define GTS_DISPATCH_LPR(VEC_, LPR_VAL, ...)                \
+  switch (LPR_VAL) {                                        \
+    case 1: { constexpr int LPR = 1; __VA_ARGS__; } break;  \
+    case 2: { constexpr int LPR = 2; __VA_ARGS__; } break;  \
+    case 4: { constexpr int LPR = 4; __VA_ARGS__; } break;  \
+    case 8: { constexpr int LPR = 8; __VA_ARGS__; } break;  \
+    case 16: { constexpr int LPR = 16; __VA_ARGS__; } break; \
+    case 32: { constexpr int LPR = 32; __VA_ARGS__; } break; \
+    default: { constexpr int LPR = 64; __VA_ARGS__; } break; \
+  }
+
+#define GTS_DISPATCH_GEOM(G, ...)                                   \
+  if ((G).vec == 4) {                                               \
+    constexpr int VEC = 4;                                          \
+    GTS_DISPATCH_LPR(4, (G).lpr, __VA_ARGS__)                       \
+  } else {                                                          \
+    constexpr int VEC = 1;                                          \
+    GTS_DISPATCH_LPR(1, (G).lpr, __VA_ARGS__)                       \
+  }
+

@@ -1,0 +1,99 @@
+"""Dataset of preprocessed MRIs and the mini-batch collate function for the GNN path.
+
+Counterpart of /root/reference/data_processing/data_loader.py:38-115,165-169.  Same class
+name, constructor flags, item layout `(mri_id, graph, features[, labels])` and collate
+output `(ids, batched_graph, FloatTensor, LongTensor)`; the graph objects are `gts.Graph`
+(int32 CSR, built once per sample) instead of DGLGraphs.
+
+One addition: parsed samples are cached in memory (`cache_graphs=True`) — the reference
+re-parses JSON -> networkx -> graph for every sample of every epoch, which would starve the
+GPU path long before its kernels matter.
+"""
+import glob
+import os
+
+import numpy as np
+import torch
+
+import gts
+from data_processing import graph_io, nifti_io
+
+
+class ImageGraphDataset(torch.utils.data.Dataset):
+    """Iterates the sample folders written by the preprocessing script: each holds
+    `{id}_nxgraph.json`, `{id}_supervoxels.nii.gz`, `{id}_input.nii.gz`, optionally
+    `{id}_label.nii.gz` and `{id}_crop.npy`."""
+
+    def __init__(self, dataset_root_dir, mri_start_string, read_image=True, read_graph=True,
+                 read_label=True, cache_graphs=True):
+        self.dataset_root_dir = dataset_root_dir
+        self.all_ids = self.get_all_mris_in_dataset(dataset_root_dir, mri_start_string)
+        self.read_image = read_image
+        self.read_graph = read_graph
+        self.read_label = read_label
+        assert self.read_graph or self.read_image
+        self._graph_cache = {} if cache_graphs else None
+
+    def get_all_mris_in_dataset(self, dataset_root_dir, mri_start_string):
+        folders = glob.glob(f"{dataset_root_dir}**/{mri_start_string}*/", recursive=True)
+        print(f"Found {len(folders)} MRIs")
+        return [fp.split(os.sep)[-2] for fp in folders]
+
+    def _path(self, mri_id, suffix):
+        return f"{self.dataset_root_dir}{os.sep}{mri_id}{os.sep}{mri_id}{suffix}"
+
+    def get_one(self, mri_id):
+        parts = []
+        if self.read_graph:
+            parts += self.get_graph(mri_id)
+        if self.read_image:
+            parts += self.get_image(mri_id)
+        return (mri_id, *parts)
+
+    def get_graph(self, mri_id):
+        """networkx JSON -> (graph, features [N,F] float64, labels [N]) ; graph.ndata['norm'] =
+        in_degree^-0.5 with inf -> 0, shape [N,1] (reference data_loader.py:67-83)."""
+        if self._graph_cache is not None and mri_id in self._graph_cache:
+            return list(self._graph_cache[mri_id])
+        nx_graph = graph_io.load_networkx_graph(self._path(mri_id, "_nxgraph.json"))
+        features = np.array([nx_graph.nodes[n]["features"] for n in nx_graph.nodes])
+        G = gts.from_networkx(nx_graph)
+        norm = torch.pow(G.in_degrees().float(), -0.5)
+        norm[torch.isinf(norm)] = 0
+        G.ndata["norm"] = norm.unsqueeze(1)
+        item = [G, features]
+        if self.read_label:
+            item.append(np.array([nx_graph.nodes[n]["label"] for n in nx_graph.nodes]))
+        if self._graph_cache is not None:
+            self._graph_cache[mri_id] = tuple(item)
+        return item
+
+    def get_voxel_labels(self, mri_id):
+        return nifti_io.read_nifti(self._path(mri_id, "_label.nii.gz"), np.int16)
+
+    def get_image(self, mri_id):
+        img = nifti_io.read_nifti(self._path(mri_id, "_input.nii.gz"), np.float32)
+        return [img, self.get_voxel_labels(mri_id)] if self.read_label else [img]
+
+    def get_supervoxel_partitioning(self, mri_id):
+        return nifti_io.read_nifti(self._path(mri_id, "_supervoxels.nii.gz"), np.int16)
+
+    def get_crop(self, mri_id):
+        return tuple(np.load(self._path(mri_id, "_crop.npy"), allow_pickle=True))
+
+    def __iter__(self):
+        return (self.get_one(mri_id) for mri_id in self.all_ids)
+
+    def __getitem__(self, index):
+        return self.get_one(self.all_ids[index])
+
+    def __len__(self):
+        return len(self.all_ids)
+
+
+def minibatch_graphs(samples):
+    """Collate [(id, graph, feats, labels), ...] into one block-diagonal batch
+    (reference data_loader.py:165-169)."""
+    mri_ids, graphs, features, labels = map(list, zip(*samples))
+    return (mri_ids, gts.batch(graphs), torch.FloatTensor(np.concatenate(features)),
+            torch.LongTensor(np.concatenate(labels)))

@@ -1,0 +1,99 @@
+"""ctypes binding of libgts_hip.so (C ABI declared in include/gts_hip.h).
+
+There is NO CPU fallback: if the library is missing or a tensor is not on an AMD GPU the
+call raises.  The oracle under /oracle is never reachable from here.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgts_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "gts_hip.h")
+ABI_VERSION = 1
+
+_p = ctypes.c_void_p
+_i32 = ctypes.c_int32
+_i64 = ctypes.c_int64
+_f32 = ctypes.c_float
+
+# name -> argtypes (restype is int32 unless noted)
+SIGNATURES = {
+    "gts_abi_version": [],
+    "gts_error_string": [_i32],
+    "gts_spmm_max_fwd_f32": [_p, _p, _p, _p, _p, _i32, _i64, _i64, _p],
+    "gts_spmm_max_bwd_f32": [_p, _p, _p, _p, _p, _i32, _p, _p, _i64, _i64, _p],
+    "gts_spmm_sum_f32": [_p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _p],
+    "gts_gat_fwd_f32": [_p, _p, _p, _p, _p, _f32, _p, _p, _i64, _i64, _i64, _p],
+    "gts_gat_bwd_edge_f32": [_p, _p, _p, _p, _p, _p, _p, _f32, _p, _p, _i64, _i64, _i64, _p],
+    "gts_gat_bwd_src_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
+    "gts_project_rows_i16": [_p, _p, _p, _p, _i64, _i64, _i32, _p],
+    "gts_project_argmax_i16": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
+}
+
+_lib = None
+
+
+class GtsError(RuntimeError):
+    pass
+
+
+def declared_symbols(header_path=HEADER_PATH):
+    """Every function name declared in include/gts_hip.h."""
+    with open(header_path) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(gts_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load the HIP library once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GtsError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (hipcc, gfx950). "
+            "The gts operators have no CPU or PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError -> the .so is stale; surface it
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == "gts_error_string" else _i32
+    if lib.gts_abi_version() != ABI_VERSION:
+        raise GtsError(f"libgts_hip.so ABI {lib.gts_abi_version()} != expected {ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().gts_error_string(code)
+        raise GtsError(f"{what} failed with code {code}: {msg.decode() if msg else '?'}")
+
+
+def require_device(*tensors):
+    """All tensors must live on one HIP device and be contiguous."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise GtsError("gts operators run on MI355X only: got a CPU tensor "
+                           "(there is no CPU fallback; use the oracle in tests)")
+        if not t.is_contiguous():
+            raise GtsError("gts operators need contiguous tensors")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise GtsError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,105 @@
+"""Data-parallel training support: one process per MI355X, RCCL over xGMI.
+
+The reference is single-device (model/gnn_model.py:23); this is the new exchange step of
+the path.  Graphs are independent samples, so ranks never exchange
+activations — only one all-reduce per optimizer step over ONE flat fp32 buffer that holds
+every parameter gradient plus two scalars:
+
+    flat = [ grad(theta) ... | sum_i w[y_i] | sum_i w[y_i] * nll_i ]
+
+`CrossEntropyLoss(weight=w)` (model/gnn_model.py:30) is a weighted mean, so the global-batch
+gradient is  (sum over ranks of grad(numerator_r)) / (sum over ranks of denominator_r), NOT
+the average of per-rank mean-loss gradients.  Each rank therefore back-propagates its local
+numerator (reduction='sum'), the numerators/denominators ride in the same all-reduce, and
+the division happens once afterwards.  The payload is ~5 MB: latency-bound, a single
+collective, no bucketing needed.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+
+def world():
+    """(rank, world_size) of the default process group, (0, 1) when not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_ADDR / MASTER_PORT).  backend defaults to 'nccl' (= RCCL on ROCm) when a GPU is
+    visible, else 'gloo'.  Returns (rank, world_size, local_rank)."""
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size > 1 and not dist.is_initialized():
+        use_gpu = torch.cuda.is_available()
+        if use_gpu:
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        kwargs = {}
+        if use_gpu:
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank,
+                                world_size=world_size, **kwargs)
+    return rank, world_size, local_rank
+
+
+def shard_indices(perm, step, per_rank, rank, world_size):
+    """Indices of rank `rank` for global step `step`: the global batch is
+    perm[step*G:(step+1)*G] with G = per_rank*world_size, dealt round-robin (r::W)."""
+    g = per_rank * world_size
+    return list(perm[step * g:(step + 1) * g][rank::world_size])
+
+
+class FlatGradSync:
+    """Owns the flat gradient buffer; parameters' .grad are views into it."""
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.n_grad = n
+        self.flat = torch.zeros(n + 2, dtype=torch.float32, device=dev)
+        self.group = group
+        off = 0
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("FlatGradSync needs fp32 parameters on one device")
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_grad(self):
+        """Replaces optimizer.zero_grad(): keeps the .grad views alive."""
+        self.flat.zero_()
+        off = 0
+        for p in self.params:  # re-attach in case something set a grad to None
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def weighted_ce_backward(self, logits, labels, class_weights):
+        """Back-propagate the local numerator and stash (denominator, numerator)."""
+        num = F.cross_entropy(logits, labels, weight=class_weights, reduction="sum")
+        den = class_weights[labels].sum()
+        num.backward()
+        self.flat[self.n_grad] = den.detach()
+        self.flat[self.n_grad + 1] = num.detach()
+
+    def all_reduce_and_normalise(self):
+        """One collective; afterwards every rank holds the exact global-batch gradient.
+        Returns the global weighted-mean loss (0-dim tensor, no host sync)."""
+        _, w = world()
+        if w > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        den = self.flat[self.n_grad]
+        loss = self.flat[self.n_grad + 1] / den
+        self.flat[:self.n_grad].div_(den)
+        return loss

@@ -1,0 +1,217 @@
+"""Graph container that crosses the host/device boundary of the GNN path.
+
+Stands in for the DGLGraph objects produced by data_processing/data_loader.py:72
+(`dgl.from_networkx`) and :168 (`dgl.batch`) of the reference and consumed by
+model/networks.py:32-36,60-66 (`layer(graph, h)`).  Duck-typed surface kept for the
+callers: `.to(device)`, `.in_degrees()`, `.number_of_edges()`, `.number_of_nodes()`,
+`.ndata[...]`, `.batch_num_nodes()`, plus the constructors `from_networkx` / `batch`.
+
+Layout (all int32, built once on the host, uploaded once per device):
+  COO           src[e], dst[e]           edges in insertion order (DGL edge ids)
+  in-CSR        indptr[N+1], indices[E]  rows = destinations; a row lists its sources in COO
+                                         order (stable sort on dst == DGL's COO->CSC)
+  out-CSR       t_indptr, t_indices      rows = sources, entries = destinations (stable on src)
+  t_slot[e']    position of out-CSR edge e' inside its destination's in-CSR row
+  t_pos[e']     absolute in-CSR position of out-CSR edge e'  (= indptr[dst] + t_slot)
+The max-pool argmax is stored as a slot (uint8 when max in-degree <= 254), which is why
+the backward needs t_slot; GAT's backward reads per-edge data through t_pos.
+"""
+import numpy as np
+import torch
+
+_I32_MAX = 2 ** 31 - 1
+
+
+class _DeviceCSR:
+    """Device-resident int32 arrays + degree vectors of one Graph."""
+
+    __slots__ = ("indptr", "indices", "t_indptr", "t_indices", "t_slot", "t_pos",
+                 "deg_clamped", "deg_plus1", "device")
+
+    def __init__(self, g, device):
+        def up(a):
+            return torch.from_numpy(a).to(device, non_blocking=False)
+
+        self.device = device
+        self.indptr = up(g.indptr)
+        self.indices = up(g.indices)
+        self.t_indptr = up(g.t_indptr)
+        self.t_indices = up(g.t_indices)
+        self.t_slot = up(g.t_slot)
+        self.t_pos = up(g.t_pos)
+        deg = np.diff(g.indptr).astype(np.float32)
+        self.deg_clamped = up(np.maximum(deg, np.float32(1)))
+        self.deg_plus1 = up(deg + np.float32(1))
+
+
+class Graph:
+    def __init__(self, src, dst, num_nodes, batch_num_nodes=None, _prebuilt=None):
+        self.src = np.ascontiguousarray(src, dtype=np.int32)
+        self.dst = np.ascontiguousarray(dst, dtype=np.int32)
+        self.n = int(num_nodes)
+        if self.src.shape != self.dst.shape or self.src.ndim != 1:
+            raise ValueError("src/dst must be 1-D arrays of equal length")
+        if self.n > _I32_MAX or self.src.size > _I32_MAX:
+            raise ValueError("graph too large for int32 CSR")
+        if self.src.size and (min(self.src.min(), self.dst.min()) < 0 or
+                              max(self.src.max(), self.dst.max()) >= self.n):
+            raise ValueError("edge endpoint outside [0, num_nodes)")
+        self._batch_num_nodes = list(batch_num_nodes) if batch_num_nodes is not None else [self.n]
+        self.ndata = {}
+        self.device = torch.device("cpu")
+        self._dev_cache = {}
+        if _prebuilt is not None:
+            (self.indptr, self.indices, self.t_indptr, self.t_indices, self.t_slot,
+             self.t_pos) = _prebuilt
+        else:
+            self._build_csr()
+        deg = np.diff(self.indptr)
+        self.max_in_degree = int(deg.max()) if deg.size else 0
+        self.min_in_degree = int(deg.min()) if deg.size else 0
+
+    # ------------------------------------------------------------------ construction
+    def _build_csr(self):
+        n, e = self.n, self.src.size
+        order = np.argsort(self.dst, kind="stable")
+        self.indices = np.ascontiguousarray(self.src[order])
+        counts = np.bincount(self.dst, minlength=n).astype(np.int64)
+        self.indptr = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum(counts, out=self.indptr[1:])
+        # absolute in-CSR position of every COO edge
+        pos_of_edge = np.empty(e, dtype=np.int32)
+        pos_of_edge[order] = np.arange(e, dtype=np.int32)
+        torder = np.argsort(self.src, kind="stable")
+        self.t_indices = np.ascontiguousarray(self.dst[torder])
+        tcounts = np.bincount(self.src, minlength=n).astype(np.int64)
+        self.t_indptr = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum(tcounts, out=self.t_indptr[1:])
+        self.t_pos = np.ascontiguousarray(pos_of_edge[torder])
+        self.t_slot = (self.t_pos - self.indptr[self.t_indices]).astype(np.int32)
+
+    # ------------------------------------------------------------------ DGL-like surface
+    def number_of_nodes(self):
+        return self.n
+
+    num_nodes = number_of_nodes
+
+    def number_of_edges(self):
+        return int(self.src.size)
+
+    num_edges = number_of_edges
+
+    def batch_num_nodes(self):
+        return torch.tensor(self._batch_num_nodes, dtype=torch.int64)
+
+    @property
+    def batch_size(self):
+        return len(self._batch_num_nodes)
+
+    def in_degrees(self):
+        return torch.from_numpy(np.diff(self.indptr).astype(np.int64)).to(self.device)
+
+    def out_degrees(self):
+        return torch.from_numpy(np.diff(self.t_indptr).astype(np.int64)).to(self.device)
+
+    def edges(self):
+        return (torch.from_numpy(self.src.astype(np.int64)).to(self.device),
+                torch.from_numpy(self.dst.astype(np.int64)).to(self.device))
+
+    def to(self, device, **_kwargs):
+        """Return a view of this graph on `device`.  Host arrays are shared; the device copy
+        of the CSR is made once per (graph, device) and reused by later `.to` calls."""
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        out = Graph.__new__(Graph)
+        out.__dict__.update(self.__dict__)
+        out.device = device
+        out.ndata = {k: v.to(device) for k, v in self.ndata.items()}
+        return out
+
+    def dev(self):
+        """Device CSR for self.device (uploaded lazily, cached on the shared cache)."""
+        if self.device.type != "cuda":
+            raise RuntimeError("Graph is on the CPU: call graph.to('cuda') first "
+                               "(the gts operators have no CPU path)")
+        d = self._dev_cache.get(self.device)
+        if d is None:
+            d = _DeviceCSR(self, self.device)
+            self._dev_cache[self.device] = d
+        return d
+
+    @property
+    def arg_bytes(self):
+        return 1 if self.max_in_degree <= 254 else 4
+
+    def __repr__(self):
+        return (f"Graph(num_nodes={self.n}, num_edges={self.number_of_edges()}, "
+                f"batch_size={self.batch_size}, device={self.device})")
+
+
+def graph(data, num_nodes=None):
+    """graph((src, dst), num_nodes) — COO constructor (dgl.graph counterpart)."""
+    src, dst = data
+    src = np.asarray(src)
+    dst = np.asarray(dst)
+    if num_nodes is None:
+        num_nodes = int(max(src.max(initial=-1), dst.max(initial=-1)) + 1)
+    return Graph(src, dst, num_nodes)
+
+
+def from_networkx(nx_graph):
+    """Counterpart of dgl.from_networkx as used at data_processing/data_loader.py:72.
+
+    Nodes are relabelled to 0..N-1 in sorted order, an undirected graph contributes both
+    directions of every pair (a self-loop once), and the COO edge order is that of
+    `to_directed().edges()` of the relabelled graph: sources in node-iteration order (=
+    ascending when the nodes were inserted in sorted order, as mri2graph/graphgen.py does),
+    targets in adjacency order.  Edge and node attributes are not carried over (the
+    reference passes none)."""
+    import networkx as nx
+
+    g = nx.convert_node_labels_to_integers(nx_graph, ordering="sorted")
+    if not g.is_directed():
+        g = g.to_directed()
+    e = g.number_of_edges()
+    coo = np.fromiter((x for uv in g.edges() for x in uv), dtype=np.int64, count=2 * e)
+    coo = coo.reshape(e, 2)
+    return Graph(coo[:, 0], coo[:, 1], g.number_of_nodes())
+
+
+def batch(graphs):
+    """Counterpart of dgl.batch (data_processing/data_loader.py:168): block-diagonal union,
+    node ids of graph j shifted by sum_{i<j} N_i, edges concatenated in graph order.
+    Both CSRs of the union are the shifted concatenations of the members' CSRs (a stable
+    sort of the concatenated COO gives exactly that), so nothing is re-sorted."""
+    graphs = list(graphs)
+    if not graphs:
+        raise ValueError("batch() needs at least one graph")
+    node_off = np.cumsum([0] + [g.n for g in graphs])
+    edge_off = np.cumsum([0] + [g.number_of_edges() for g in graphs])
+    if node_off[-1] > _I32_MAX or edge_off[-1] > _I32_MAX:
+        raise ValueError("batched graph too large for int32 CSR")
+    no32 = node_off.astype(np.int32)
+    eo32 = edge_off.astype(np.int32)
+
+    def cat_ptr(name):
+        parts = [getattr(g, name)[:-1] + eo32[i] for i, g in enumerate(graphs)]
+        parts.append(np.array([eo32[-1]], dtype=np.int32))
+        return np.concatenate(parts).astype(np.int32, copy=False)
+
+    def cat_nodes(name):
+        return np.concatenate([getattr(g, name) + no32[i] for i, g in enumerate(graphs)])
+
+    prebuilt = (
+        cat_ptr("indptr"), cat_nodes("indices"), cat_ptr("t_indptr"), cat_nodes("t_indices"),
+        np.concatenate([g.t_slot for g in graphs]),
+        np.concatenate([g.t_pos + eo32[i] for i, g in enumerate(graphs)]),
+    )
+    sizes = [s for g in graphs for s in g._batch_num_nodes]
+    out = Graph(cat_nodes("src"), cat_nodes("dst"), int(node_off[-1]), batch_num_nodes=sizes,
+                _prebuilt=tuple(np.ascontiguousarray(a, dtype=np.int32) for a in prebuilt))
+    common = set(graphs[0].ndata)
+    for g in graphs[1:]:
+        common &= set(g.ndata)
+    for k in common:
+        out.ndata[k] = torch.cat([g.ndata[k] for g in graphs], dim=0)
+    return out

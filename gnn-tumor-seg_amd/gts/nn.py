@@ -1,0 +1,194 @@
+"""SAGEConv / GATConv for MI355X: the layer modules model/networks.py builds its stacks from.
+
+Counterparts of dgl.nn.pytorch.conv.SAGEConv / dgl.nn.pytorch.GATConv as constructed at
+/root/reference/model/networks.py:25,28,30 and :46,52,56 — same constructor arguments (in
+the positional order the reference uses), same parameter names and shapes in
+`state_dict()`, same initialisation scheme; the arithmetic runs in the HIP kernels of
+libgts_hip.so (neighbour reducers, attention) plus dense fp32 GEMMs.
+
+The pool layer is ONE autograd node (`_SagePoolLayer`): forward and backward are written
+out by hand so that the ReLU of fc_pool is folded into the max-pool backward kernel, the
+argmax is kept as one byte per element, and nothing but (h, p, m, arg, out) is retained.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import dense, ops
+
+
+class GraphError(RuntimeError):
+    """Counterpart of dgl.DGLError for the checks the layers make."""
+
+
+def _is_relu(fn):
+    return fn in (F.relu, torch.relu, torch.nn.functional.relu)
+
+
+class _SagePoolLayer(torch.autograd.Function):
+    """out = act(h Ws^T + maxpool_g(relu(h Wp^T + bp)) Wn^T + b)."""
+
+    @staticmethod
+    def forward(ctx, g, h, w_pool, b_pool, w_self, w_neigh, bias, relu_out, need_bwd):
+        h = h.contiguous()
+        p = dense.linear_fwd(h, w_pool, bias=b_pool, relu=True)
+        m, arg = ops.spmm_max_fwd(g, p, want_arg=need_bwd)
+        out = dense.linear_fwd(h, w_self, m, w_neigh, bias=bias, relu=relu_out)
+        if need_bwd:
+            ctx.g, ctx.relu_out = g, relu_out
+            ctx.save_for_backward(h, p, m, arg, out if relu_out else None,
+                                  w_pool, w_self, w_neigh)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        h, p, m, arg, out, w_pool, w_self, w_neigh = ctx.saved_tensors
+        g = dense.relu_bwd(gout, out) if ctx.relu_out else gout.contiguous()
+        need = ctx.needs_input_grad
+        g_bias = dense.bias_grad(g) if need[6] else None
+        g_ws = dense.linear_bwd_weight(g, h) if need[4] else None
+        g_wn = dense.linear_bwd_weight(g, m) if need[5] else None
+        gm = dense.linear_bwd_input(g, w_neigh)
+        gp = ops.spmm_max_bwd(ctx.g, gm, arg, relu_src=p)      # fused ReLU'(p)
+        g_bp = dense.bias_grad(gp) if need[3] else None
+        g_wp = dense.linear_bwd_weight(gp, h) if need[2] else None
+        gh = None
+        if need[1]:
+            gh = dense.linear_bwd_input(g, w_self)
+            gh = dense.linear_bwd_input(gp, w_pool, out=gh)
+        return None, gh, g_wp, g_bp, g_ws, g_wn, g_bias, None, None
+
+
+class SAGEConv(nn.Module):
+    """GraphSAGE layer, aggregator_type in {'mean', 'gcn', 'pool'} ('lstm' is not built:
+    no reference script reaches it, model/networks.py:68-81)."""
+
+    def __init__(self, in_feats, out_feats, aggregator_type, feat_drop=0.0, bias=True, norm=None,
+                 activation=None):
+        super().__init__()
+        if aggregator_type not in ("mean", "gcn", "pool"):
+            raise KeyError(f"Invalid aggregator_type. Must be one of mean, gcn, pool. "
+                           f"But got {aggregator_type!r} instead.")
+        self._in_src_feats = self._in_dst_feats = int(in_feats)
+        self._out_feats = int(out_feats)
+        self._aggre_type = aggregator_type
+        self.norm = norm
+        self.feat_drop = nn.Dropout(feat_drop)
+        self.activation = activation
+        if aggregator_type == "pool":
+            self.fc_pool = nn.Linear(in_feats, in_feats)
+        if aggregator_type != "gcn":
+            self.fc_self = nn.Linear(in_feats, out_feats, bias=False)
+        self.fc_neigh = nn.Linear(in_feats, out_feats, bias=False)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_feats))
+        else:
+            self.register_buffer("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        gain = nn.init.calculate_gain("relu")
+        if self._aggre_type == "pool":
+            nn.init.xavier_uniform_(self.fc_pool.weight, gain=gain)
+        if self._aggre_type != "gcn":
+            nn.init.xavier_uniform_(self.fc_self.weight, gain=gain)
+        nn.init.xavier_uniform_(self.fc_neigh.weight, gain=gain)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # Older DGL checkpoints carry fc_self.bias / fc_neigh.bias instead of one `bias`.
+        legacy = [prefix + "fc_self.bias", prefix + "fc_neigh.bias"]
+        if prefix + "bias" not in state_dict and any(k in state_dict for k in legacy):
+            folded = sum(state_dict.pop(k) for k in legacy if k in state_dict)
+            state_dict[prefix + "bias"] = folded
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def forward(self, graph, feat):
+        h = self.feat_drop(feat)
+        fused_relu = _is_relu(self.activation)
+        if self._aggre_type == "pool":
+            bias = self.bias if self.bias is not None else torch.zeros(
+                self._out_feats, dtype=h.dtype, device=h.device)
+            need_bwd = torch.is_grad_enabled() and (
+                h.requires_grad or any(p.requires_grad for p in self.parameters()))
+            rst = _SagePoolLayer.apply(graph, h, self.fc_pool.weight, self.fc_pool.bias,
+                                       self.fc_self.weight, self.fc_neigh.weight, bias,
+                                       fused_relu, need_bwd)
+        else:
+            lin_before_mp = self._in_src_feats > self._out_feats
+            src = self.fc_neigh(h) if lin_before_mp else h
+            neigh = ops.spmm_reduce(graph, src, self._aggre_type)
+            if not lin_before_mp:
+                neigh = self.fc_neigh(neigh)
+            rst = neigh if self._aggre_type == "gcn" else self.fc_self(h) + neigh
+            if self.bias is not None:
+                rst = rst + self.bias
+            if fused_relu:
+                rst = torch.relu(rst)
+        if self.activation is not None and not fused_relu:
+            rst = self.activation(rst)
+        if self.norm is not None:
+            rst = self.norm(rst)
+        return rst
+
+
+class GATConv(nn.Module):
+    """Graph attention layer (positional order as called at model/networks.py:46-58)."""
+
+    def __init__(self, in_feats, out_feats, num_heads, feat_drop=0.0, attn_drop=0.0,
+                 negative_slope=0.2, residual=False, activation=None,
+                 allow_zero_in_degree=False, bias=True):
+        super().__init__()
+        self._in_feats, self._out_feats, self._num_heads = int(in_feats), int(out_feats), int(num_heads)
+        self._allow_zero_in_degree = allow_zero_in_degree
+        self.fc = nn.Linear(in_feats, out_feats * num_heads, bias=False)
+        self.attn_l = nn.Parameter(torch.empty(1, num_heads, out_feats))
+        self.attn_r = nn.Parameter(torch.empty(1, num_heads, out_feats))
+        self.feat_drop = nn.Dropout(feat_drop)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.negative_slope = negative_slope
+        if bias:
+            self.bias = nn.Parameter(torch.empty(num_heads * out_feats))
+        else:
+            self.register_buffer("bias", None)
+        if residual:
+            if in_feats != out_feats * num_heads:
+                self.res_fc = nn.Linear(in_feats, num_heads * out_feats, bias=False)
+            else:
+                self.res_fc = nn.Identity()
+        else:
+            self.register_buffer("res_fc", None)
+        self.activation = activation
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        gain = nn.init.calculate_gain("relu")
+        nn.init.xavier_normal_(self.fc.weight, gain=gain)
+        nn.init.xavier_normal_(self.attn_l, gain=gain)
+        nn.init.xavier_normal_(self.attn_r, gain=gain)
+        if self.bias is not None:
+            nn.init.constant_(self.bias, 0)
+        if isinstance(self.res_fc, nn.Linear):
+            nn.init.xavier_normal_(self.res_fc.weight, gain=gain)
+
+    def forward(self, graph, feat):
+        if not self._allow_zero_in_degree and graph.min_in_degree == 0:
+            raise GraphError(
+                "There are 0-in-degree nodes in the graph, output for those nodes will be invalid. "
+                "Adding self-loop on the input graph resolves the issue; setting "
+                "allow_zero_in_degree=True suppresses the check.")
+        if self.attn_drop.p > 0 and self.training:
+            raise NotImplementedError("attention dropout is not built (the reference never sets it: "
+                                      "model/networks.py:77-78 passes no dropout to GAT)")
+        n = feat.shape[0]
+        h = self.feat_drop(feat)
+        ft = self.fc(h).view(n, self._num_heads, self._out_feats)
+        el = (ft * self.attn_l).sum(dim=-1)
+        er = (ft * self.attn_r).sum(dim=-1)
+        rst = ops.gat_aggregate(graph, ft, el, er, self.negative_slope)
+        if self.res_fc is not None:
+            rst = rst + self.res_fc(h).view(n, -1, self._out_feats)
+        if self.bias is not None:
+            rst = rst + self.bias.view(1, self._num_heads, self._out_feats)
+        if self.activation is not None:
+            rst = self.activation(rst)
+        return rst

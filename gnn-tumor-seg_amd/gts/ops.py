@@ -1,0 +1,199 @@
+"""Python wrappers + autograd glue over the C-ABI HIP kernels (include/gts_hip.h).
+
+Every function here enqueues on torch's current HIP stream and returns torch tensors that
+own the memory; nothing falls back to PyTorch or the CPU when the library is missing.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, ptr, require_device
+
+_ARG_DTYPE = {1: torch.uint8, 4: torch.int32}
+
+
+def _f32(*tensors):
+    for t in tensors:
+        if t is not None and t.dtype != torch.float32:
+            raise _lib.GtsError(f"gts kernels are fp32: got {t.dtype}")
+
+
+# ---------------------------------------------------------------- raw kernel calls
+def spmm_max_fwd(g, x, want_arg=True):
+    """K1.  x [N,F] -> (out [N,F], arg [N,F] slot ids or None)."""
+    x = x.contiguous()
+    _f32(x)
+    require_device(x)
+    d = g.dev()
+    n, f = g.n, x.shape[1]
+    if x.shape[0] != n:
+        raise _lib.GtsError(f"feature rows {x.shape[0]} != graph nodes {n}")
+    out = torch.empty((n, f), dtype=torch.float32, device=x.device)
+    ab = g.arg_bytes if want_arg else 0
+    arg = torch.empty((n, f), dtype=_ARG_DTYPE[ab], device=x.device) if want_arg else None
+    check(_lib.load().gts_spmm_max_fwd_f32(ptr(d.indptr), ptr(d.indices), ptr(x), ptr(out), ptr(arg),
+                                           ab, n, f, current_stream()), "gts_spmm_max_fwd_f32")
+    return out, arg
+
+
+def spmm_max_bwd(g, gout, arg, relu_src=None):
+    """K2.  gout [N,F], arg from spmm_max_fwd -> gx [N,F]; optional fused ReLU mask."""
+    gout = gout.contiguous()
+    _f32(gout, relu_src)
+    require_device(gout, arg, relu_src)
+    d = g.dev()
+    n, f = g.n, gout.shape[1]
+    gx = torch.empty((n, f), dtype=torch.float32, device=gout.device)
+    check(_lib.load().gts_spmm_max_bwd_f32(ptr(d.t_indptr), ptr(d.t_indices), ptr(d.t_slot), ptr(gout),
+                                           ptr(arg), arg.element_size(), ptr(relu_src), ptr(gx), n, f,
+                                           current_stream()), "gts_spmm_max_bwd_f32")
+    return gx
+
+
+def spmm_sum_raw(g, x, transposed=False, div_in=None, div_out=None, add_self=False):
+    """K3/K4.  Generic sum reducer over the in-CSR (or the out-CSR when transposed)."""
+    x = x.contiguous()
+    _f32(x, div_in, div_out)
+    require_device(x, div_in, div_out)
+    d = g.dev()
+    indptr, indices = (d.t_indptr, d.t_indices) if transposed else (d.indptr, d.indices)
+    n = g.n
+    if x.shape[0] != n:
+        raise _lib.GtsError(f"feature rows {x.shape[0]} != graph nodes {n}")
+    if x.dim() != 2:
+        raise _lib.GtsError("spmm_sum expects a 2-D feature matrix")
+    f = x.shape[1]
+    out = torch.empty_like(x)
+    check(_lib.load().gts_spmm_sum_f32(ptr(indptr), ptr(indices), ptr(x), ptr(out), ptr(div_in), ptr(div_out),
+                                       1 if add_self else 0, n, f, current_stream()), "gts_spmm_sum_f32")
+    return out
+
+
+# ---------------------------------------------------------------- autograd: reducers
+class _SpMMMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, x):
+        out, arg = spmm_max_fwd(g, x, want_arg=True)
+        ctx.g = g
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (arg,) = ctx.saved_tensors
+        return None, spmm_max_bwd(ctx.g, gout, arg)
+
+
+class _SpMMReduce(torch.autograd.Function):
+    """mode: 'sum' | 'mean' | 'gcn' (DGL reducers reached from SAGEConv)."""
+
+    @staticmethod
+    def forward(ctx, g, x, mode):
+        ctx.g, ctx.mode = g, mode
+        d = g.dev()
+        if mode == "sum":
+            return spmm_sum_raw(g, x)
+        if mode == "mean":
+            return spmm_sum_raw(g, x, div_out=d.deg_clamped)
+        if mode == "gcn":
+            return spmm_sum_raw(g, x, div_out=d.deg_plus1, add_self=True)
+        raise ValueError(mode)
+
+    @staticmethod
+    def backward(ctx, gout):
+        g, mode = ctx.g, ctx.mode
+        d = g.dev()
+        if mode == "sum":
+            gx = spmm_sum_raw(g, gout, transposed=True)
+        elif mode == "mean":
+            gx = spmm_sum_raw(g, gout, transposed=True, div_in=d.deg_clamped)
+        else:
+            gx = spmm_sum_raw(g, gout, transposed=True, div_in=d.deg_plus1, add_self=True)
+        return None, gx, None
+
+
+def spmm_max(g, x):
+    return _SpMMMax.apply(g, x)
+
+
+def spmm_reduce(g, x, mode):
+    return _SpMMReduce.apply(g, x, mode)
+
+
+# ---------------------------------------------------------------- autograd: GAT
+class _GATAggregate(torch.autograd.Function):
+    """K5-K8.  (ft [N,H,D], el [N,H], er [N,H]) -> out [N,H,D]."""
+
+    @staticmethod
+    def forward(ctx, g, ft, el, er, negative_slope):
+        ft, el, er = ft.contiguous(), el.contiguous(), er.contiguous()
+        _f32(ft, el, er)
+        require_device(ft, el, er)
+        d = g.dev()
+        n, h, dim = ft.shape
+        out = torch.empty_like(ft)
+        attn = torch.empty((g.number_of_edges(), h), dtype=torch.float32, device=ft.device)
+        check(_lib.load().gts_gat_fwd_f32(ptr(d.indptr), ptr(d.indices), ptr(ft), ptr(el), ptr(er),
+                                          float(negative_slope), ptr(out), ptr(attn), n, h, dim,
+                                          current_stream()), "gts_gat_fwd_f32")
+        ctx.g, ctx.slope = g, float(negative_slope)
+        ctx.save_for_backward(ft, el, er, attn)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        ft, el, er, attn = ctx.saved_tensors
+        gout = gout.contiguous()
+        g, d = ctx.g, ctx.g.dev()
+        n, h, dim = ft.shape
+        lib = _lib.load()
+        ge = torch.empty_like(attn)
+        ger = torch.empty_like(er)
+        check(lib.gts_gat_bwd_edge_f32(ptr(d.indptr), ptr(d.indices), ptr(ft), ptr(el), ptr(er), ptr(attn),
+                                       ptr(gout), ctx.slope, ptr(ge), ptr(ger), n, h, dim,
+                                       current_stream()), "gts_gat_bwd_edge_f32")
+        gft = torch.empty_like(ft)
+        gel = torch.empty_like(el)
+        check(lib.gts_gat_bwd_src_f32(ptr(d.t_indptr), ptr(d.t_indices), ptr(d.t_pos), ptr(attn), ptr(ge),
+                                      ptr(gout), ptr(gft), ptr(gel), n, h, dim, current_stream()),
+              "gts_gat_bwd_src_f32")
+        return None, gft, gel, ger, None
+
+
+def gat_aggregate(g, ft, el, er, negative_slope):
+    return _GATAggregate.apply(g, ft, el, er, negative_slope)
+
+
+# ---------------------------------------------------------------- node -> voxel projection
+def project_rows(svs, table, bg_row):
+    """K12.  svs int16 [...], table [N, ...] with 4/8/16-byte rows, bg_row one such row.
+    Returns table_plus_bg[svs] with shape svs.shape + table.shape[1:]."""
+    require_device(svs, table, bg_row)
+    if svs.dtype != torch.int16:
+        raise _lib.GtsError("supervoxel partitioning must be int16 (mri2graph/graphgen.py:77)")
+    svs = svs.contiguous()
+    table = table.contiguous()
+    bg_row = bg_row.to(table.dtype).contiguous()
+    row_bytes = table.element_size() * (table[0].numel() if table.shape[0] else bg_row.numel())
+    if bg_row.numel() * bg_row.element_size() != row_bytes:
+        raise _lib.GtsError("background row does not match table rows")
+    out = torch.empty(tuple(svs.shape) + tuple(table.shape[1:]), dtype=table.dtype, device=svs.device)
+    check(_lib.load().gts_project_rows_i16(ptr(svs), ptr(table), ptr(bg_row), ptr(out), svs.numel(),
+                                           table.shape[0], row_bytes, current_stream()),
+          "gts_project_rows_i16")
+    return out
+
+
+def project_argmax(svs, logits, relabel=None):
+    """K12 fused: argmax over classes of the voxel's node, 0 for background; int16 out."""
+    require_device(svs, logits, relabel)
+    _f32(logits)
+    if svs.dtype != torch.int16:
+        raise _lib.GtsError("supervoxel partitioning must be int16")
+    svs, logits = svs.contiguous(), logits.contiguous()
+    if relabel is not None and (relabel.dtype != torch.int16 or relabel.numel() < logits.shape[1]):
+        raise _lib.GtsError("relabel must be int16 with one entry per class")
+    out = torch.empty(svs.shape, dtype=torch.int16, device=svs.device)
+    check(_lib.load().gts_project_argmax_i16(ptr(svs), ptr(logits), ptr(relabel), ptr(out), svs.numel(),
+                                             logits.shape[0], logits.shape[1], current_stream()),
+          "gts_project_argmax_i16")
+    return out

@@ -1,0 +1,141 @@
+"""Training / evaluation harness of the GNN on MI355X.
+
+Counterpart of /root/reference/model/gnn_model.py:21-90 — same class, constructor
+`GNN(model_type, hyperparameters, train_dataset)`, attributes (`net`, `optimizer`,
+`lr_decay`, `loss_fcn`, `train_loader`, `device`) and methods (`run_epoch() -> float`,
+`evaluate(Subset) -> (metrics[10], counts[8])`, `save_weights(folder, name)`), so
+scripts/train_gnn.py drives it unchanged.
+
+Differences that do not change results:
+  * the device must be an AMD GPU — there is no CPU path (the HIP library is the product);
+  * `ExponentialLR(..., verbose=False)` (reference :29) raises on current PyTorch; the kwarg
+    is dropped, behaviour is the same;
+  * the per-step `loss.item()` host sync (:43) becomes one read-back per epoch (same values);
+  * when torch.distributed is initialised with world_size > 1, every rank trains on its
+    share of each global batch and gradients are combined by gts.dist.FlatGradSync (exact
+    weighted-CE normalisation); world_size == 1 follows the reference's arithmetic exactly.
+"""
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from data_processing.data_loader import ImageGraphDataset, minibatch_graphs
+from data_processing.graph_io import project_nodes_to_img
+from gts import dist as gdist
+
+from . import evaluation
+from .networks import init_graph_net
+
+BATCH_SIZE = 6
+
+
+class _ShardedBatches:
+    """Epoch iterator for data-parallel runs: one shared shuffle, per-rank slices."""
+
+    def __init__(self, dataset, per_rank, rank, world_size, seed=0):
+        self.dataset, self.per_rank, self.rank, self.world = dataset, per_rank, rank, world_size
+        self.seed, self.epoch = seed, 0
+
+    def __len__(self):
+        return len(self.dataset) // (self.per_rank * self.world)
+
+    def __iter__(self):
+        gen = torch.Generator()
+        gen.manual_seed(self.seed + self.epoch)
+        self.epoch += 1
+        perm = torch.randperm(len(self.dataset), generator=gen).tolist()
+        for step in range(len(self)):
+            idx = gdist.shard_indices(perm, step, self.per_rank, self.rank, self.world)
+            yield minibatch_graphs([self.dataset[i] for i in idx])
+
+
+class GNN:
+    def __init__(self, model_type, hyperparameters, train_dataset, batch_size=BATCH_SIZE):
+        if not torch.cuda.is_available():
+            raise RuntimeError("GNN needs an AMD GPU (MI355X): the HIP kernels have no CPU fallback")
+        self.rank, self.world_size = gdist.world()
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        print("Using device", self.device)
+        class_weights = torch.FloatTensor(hyperparameters.class_weights).to(self.device)
+        self.class_weights = class_weights
+        self.net = init_graph_net(model_type, hyperparameters)
+        self.net.to(self.device)
+        self.optimizer = torch.optim.AdamW(self.net.parameters(), lr=hyperparameters.lr,
+                                           weight_decay=hyperparameters.w_decay)
+        self.lr_decay = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, hyperparameters.lr_decay,
+                                                               last_epoch=-1)
+        self.loss_fcn = torch.nn.CrossEntropyLoss(weight=class_weights)
+        self.grad_sync = None
+        if train_dataset is None:
+            self.train_loader = None
+        elif self.world_size > 1:
+            for p in self.net.parameters():  # identical replicas: rank 0's initialisation wins
+                torch.distributed.broadcast(p.data, src=0)
+            self.grad_sync = gdist.FlatGradSync(self.net.parameters())
+            self.train_loader = _ShardedBatches(train_dataset, batch_size, self.rank, self.world_size)
+        else:
+            self.train_loader = DataLoader(train_dataset, batch_size=batch_size, shuffle=True,
+                                           num_workers=0, collate_fn=minibatch_graphs)
+
+    def train_step(self, graph, features, labels):
+        """One optimizer step on device-resident inputs; returns the loss as a 0-dim tensor."""
+        logits = self.net(graph, features)
+        if self.grad_sync is None:
+            loss = self.loss_fcn(logits, labels)
+            self.optimizer.zero_grad()
+            loss.backward()
+            self.optimizer.step()
+            return loss.detach()
+        self.grad_sync.zero_grad()
+        self.grad_sync.weighted_ce_backward(logits, labels, self.class_weights)
+        loss = self.grad_sync.all_reduce_and_normalise()
+        self.optimizer.step()
+        return loss.clone()
+
+    def run_epoch(self):
+        self.net.train()
+        losses = []
+        for _ids, batch_graphs, batch_features, batch_labels in self.train_loader:
+            batch_graphs = batch_graphs.to(self.device)
+            batch_features = batch_features.to(self.device)
+            batch_labels = batch_labels.to(self.device)
+            losses.append(self.train_step(batch_graphs, batch_features, batch_labels))
+        self.lr_decay.step()
+        return np.mean(torch.stack(losses).cpu().double().numpy())
+
+    # dataset must be a torch Subset of an ImageGraphDataset (as scripts/train_gnn.py passes)
+    def evaluate(self, dataset: ImageGraphDataset):
+        assert dataset.dataset.read_label == True  # noqa: E712
+        self.net.eval()
+        # loss | node dice WT,CT,ET | voxel dice WT,CT,ET | voxel HD95 WT,CT,ET
+        metrics = np.zeros((len(dataset), 10))
+        counts = np.zeros((len(dataset), 8))
+        for i, (curr_id, curr_graph, curr_feats, curr_labels) in enumerate(dataset):
+            curr_graph = curr_graph.to(self.device)
+            curr_feats = torch.FloatTensor(curr_feats).to(self.device)
+            curr_labels = torch.LongTensor(curr_labels).to(self.device)
+            with torch.no_grad():
+                logits = self.net(curr_graph, curr_feats)
+                loss = self.loss_fcn(logits, curr_labels)
+            _, predicted_classes = torch.max(logits, dim=1)
+            predicted_classes = predicted_classes.detach().cpu().numpy()
+            metrics[i][0] = loss.item()
+            ct, res = self.calculate_all_metrics_for_brain(
+                curr_id, dataset, predicted_classes, curr_labels.detach().cpu().numpy())
+            metrics[i][1:] = res
+            counts[i] = ct
+        return np.mean(metrics, axis=0), np.sum(counts, axis=0)
+
+    def calculate_all_metrics_for_brain(self, mri_id, dataset, node_preds, node_labels):
+        label_counts = np.concatenate([evaluation.count_node_labels(node_preds),
+                                       evaluation.count_node_labels(node_labels)])
+        node_dices = evaluation.calculate_node_dices(node_preds, node_labels)
+        sv_partitioning = dataset.dataset.get_supervoxel_partitioning(mri_id)
+        true_voxels = dataset.dataset.get_voxel_labels(mri_id)
+        pred_voxels = project_nodes_to_img(sv_partitioning, node_preds)   # K12 on the GPU
+        voxel_metrics = evaluation.calculate_brats_metrics(pred_voxels, true_voxels)
+        return label_counts, np.concatenate([node_dices, voxel_metrics])
+
+    def save_weights(self, folder, name):
+        if self.rank == 0:
+            torch.save(self.net.state_dict(), f"{folder}{name}.pt")

@@ -1,0 +1,120 @@
+/*
+ * gts_hip.h — C ABI of libgts_hip.so, the MI355X (gfx950) kernels behind the GNN
+ * node-classification path of rsinghlab/GNN-Tumor-Seg.
+ *
+ * The reference has no FFI of its own: its arithmetic is reached through DGL's Python
+ * API.  Each entry point below names the reference call site (file:line under
+ * /root/reference) and the DGL operator it stands in for.
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer owned by the caller; the library allocates
+ *     nothing, frees nothing and keeps no state between calls (re-entrant);
+ *   - `stream` is a hipStream_t (NULL = default stream); work is only enqueued, never
+ *     synchronised; the device is whatever the caller made current;
+ *   - return value: 0 on success, GTS_ERR_* (<0) for a rejected argument, otherwise a
+ *     positive hipError_t from the launch.  Nothing throws or aborts;
+ *   - feature matrices are dense row-major fp32; graphs are int32 CSR
+ *     (E < 2^31, N < 2^31).  "in-CSR" = rows are destinations, entries are the
+ *     sources of their in-edges in COO order; "out-CSR" = rows are sources.
+ */
+#ifndef GTS_HIP_H
+#define GTS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GTS_OK 0
+#define GTS_ERR_NULL (-1)    /* a required pointer is NULL            */
+#define GTS_ERR_SHAPE (-2)   /* negative / overflowing / unsupported shape */
+#define GTS_ERR_ARGKIND (-3) /* unsupported arg_bytes / mode value    */
+
+/* ABI version, bumped when a signature changes. */
+int32_t gts_abi_version(void);
+/* Static string for a GTS_ERR_* / hipError_t code returned by this library. */
+const char* gts_error_string(int32_t code);
+
+/* ---- K1: copy_u + max reducer (forward) -------------------------------------------
+ * Replaces DGL update_all(copy_u('h','m'), max('m','neigh')) inside SAGEConv('pool'),
+ * reached from model/networks.py:25,28,30.
+ *   out[v,f] = max_{k} x[indices[indptr[v]+k], f]; first maximum wins (strict '<');
+ *   +-inf results and empty rows give 0 and select nothing.
+ *   arg (optional, arg_bytes = 0 -> not written): the SLOT k of the winner inside
+ *   row v, as uint8 (arg_bytes=1, slot 0xFF = none; needs max in-degree <= 254)
+ *   or int32 (arg_bytes=4, -1 = none); layout [n_dst, n_feat]. */
+int32_t gts_spmm_max_fwd_f32(const int32_t* indptr, const int32_t* indices, const float* x,
+                             float* out, void* arg, int32_t arg_bytes, int64_t n_dst,
+                             int64_t n_feat, void* stream);
+
+/* ---- K2: max reducer (backward), gather form over the out-CSR -----------------------
+ * Replaces the autograd of K1 (DGL scatters gout by argmax).
+ *   gx[u,f] = sum_{e in out(u)} [arg[t_indices[e], f] == t_slot[e]] * gout[t_indices[e], f]
+ *   t_slot[e] = position of edge e inside its destination's in-CSR row.
+ *   relu_src (optional): if given, gx[u,f] is zeroed where relu_src[u,f] <= 0
+ *   (the ReLU that precedes the pooling, SAGEConv: relu(fc_pool(h))). */
+int32_t gts_spmm_max_bwd_f32(const int32_t* t_indptr, const int32_t* t_indices,
+                             const int32_t* t_slot, const float* gout, const void* arg,
+                             int32_t arg_bytes, const float* relu_src, float* gx,
+                             int64_t n_src, int64_t n_feat, void* stream);
+
+/* ---- K3/K4: copy_u + sum / mean / gcn reducers (forward and backward) ---------------
+ * Replaces DGL update_all(copy_u, sum|mean) of SAGEConv('mean'|'gcn')
+ * (model/networks.py:73,75 via :25-30) and, on the out-CSR, their autograd.
+ *   s[v,f]   = sum_k  x[idx_k, f] / (div_in ? div_in[idx_k] : 1)   (slot order)
+ *   if add_self: s[v,f] += x[v,f] / (div_in ? div_in[v] : 1)        (needs square graph)
+ *   out[v,f] = s[v,f] / (div_out ? div_out[v] : 1)
+ * mean fwd: div_out = max(deg,1); mean bwd: out-CSR, div_in = max(deg,1);
+ * gcn  fwd: add_self, div_out = deg+1;  gcn bwd: out-CSR, add_self, div_in = deg+1. */
+int32_t gts_spmm_sum_f32(const int32_t* indptr, const int32_t* indices, const float* x,
+                         float* out, const float* div_in, const float* div_out,
+                         int32_t add_self, int64_t n_out, int64_t n_feat, void* stream);
+
+/* ---- K5-K7: GATConv attention + aggregation (forward) -------------------------------
+ * Replaces apply_edges(u_add_v) + leaky_relu + edge_softmax + update_all(u_mul_e, sum)
+ * inside GATConv, reached from model/networks.py:46,52,56.
+ *   e_k = leaky_relu(el[src_k,h] + er[v,h]);  a_k = softmax_k(e_k) over row v (max-subtracted)
+ *   out[v,h,:] = sum_k a_k * ft[src_k,h,:]
+ *   ft [n,H,D], el/er [n,H], out [n,H,D], attn [E,H] in in-CSR slot order (saved for K8). */
+int32_t gts_gat_fwd_f32(const int32_t* indptr, const int32_t* indices, const float* ft,
+                        const float* el, const float* er, float negative_slope, float* out,
+                        float* attn, int64_t n, int64_t heads, int64_t dim, void* stream);
+
+/* ---- K8: GATConv backward ------------------------------------------------------------
+ * Two passes, both atomics-free:
+ *  (1) per destination row (in-CSR):  ga_k = <gout[v,h,:], ft[src_k,h,:]>,
+ *      ge_k = a_k*(ga_k - sum_j a_j ga_j) * leaky'(el[src_k]+er[v]);  ger[v,h] = sum_k ge_k;
+ *      ge [E,H] written in in-CSR slot order.
+ *  (2) per source row (out-CSR): gft[u,h,:] = sum_{e in out(u)} a[slot(e)] * gout[dst_e,h,:],
+ *      gel[u,h] = sum_e ge[slot(e)].   t_pos[e] = absolute in-CSR position of out-edge e. */
+int32_t gts_gat_bwd_edge_f32(const int32_t* indptr, const int32_t* indices, const float* ft,
+                             const float* el, const float* er, const float* attn,
+                             const float* gout, float negative_slope, float* ge, float* ger,
+                             int64_t n, int64_t heads, int64_t dim, void* stream);
+int32_t gts_gat_bwd_src_f32(const int32_t* t_indptr, const int32_t* t_indices,
+                            const int32_t* t_pos, const float* attn, const float* ge,
+                            const float* gout, float* gft, float* gel, int64_t n,
+                            int64_t heads, int64_t dim, void* stream);
+
+/* ---- K12: node -> voxel projection ----------------------------------------------------
+ * Replaces data_processing/graph_io.py:21-24 (project_nodes_to_img) and
+ * scripts/generate_gnn_predictions.py:55-61 (save_voxel_logits):
+ *   out[i, :] = (svs[i] < 0 ? bg_row : table[svs[i], :]) for i in [0, n_vox).
+ * svs holds supervoxel ids in [-1, n_rows) (int16, mri2graph/graphgen.py:77); any
+ * negative id selects the background row, exactly numpy's table_plus_bg[-1].
+ * Rows are `row_bytes` opaque bytes (4, 8 or 16): int64 labels, fp32 x4 logits, ... */
+int32_t gts_project_rows_i16(const int16_t* svs, const void* table, const void* bg_row,
+                             void* out, int64_t n_vox, int64_t n_rows, int32_t row_bytes,
+                             void* stream);
+/* Fused argmax + projection: out[i] = argmax_c logits[svs[i], c] (first maximum, as
+ * torch.max(logits,1), generate_gnn_predictions.py:66), 0 for background; int16 out
+ * with an optional 4-entry relabel table (swap_labels_to_brats, preprocess_dataset.py:159). */
+int32_t gts_project_argmax_i16(const int16_t* svs, const float* logits, const int16_t* relabel,
+                               int16_t* out, int64_t n_vox, int64_t n_rows, int64_t n_classes,
+                               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTS_HIP_H */

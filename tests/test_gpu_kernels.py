@@ -1,0 +1,240 @@
+"""Parity of every HIP kernel (through the C ABI) with the CPU oracle, on a real MI355X.
+
+Bars: bit-exact for max aggregation (+ its argmax), for the sum/mean/gcn reducers (the
+kernels accumulate in the oracle's slot order and divide like it) and for the voxel
+projection; rtol/atol 1e-5 for the GAT attention path (device expf is not bit-identical
+to the host's)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gts
+from gts import ops, synth
+from oracle import graph_ref, torch_ref
+from tests.helpers import HAND_EDGES, HAND_X, random_coo, ref_and_gts, slots_to_sources
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib(hip_lib):
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return hip_lib
+
+
+def _hand():
+    src, dst = map(np.array, zip(*HAND_EDGES))
+    return ref_and_gts(src, dst, 6)
+
+
+def _feat(n, f, seed, integer=False):
+    gen = torch.Generator().manual_seed(seed)
+    if integer:   # small integers: many ties, exact sums
+        return torch.randint(-3, 4, (n, f), generator=gen).float()
+    return torch.randn(n, f, generator=gen)
+
+
+# ------------------------------------------------------------------ K1 / K2
+def test_max_hand_graph_bit_exact():
+    tg, g = _hand()
+    x = torch.from_numpy(HAND_X)
+    out_ref, arg_ref = torch_ref.spmm_max_with_arg(tg, x)
+    out, arg = ops.spmm_max_fwd(g.to(DEV), x.to(DEV))
+    assert torch.equal(out.cpu(), out_ref)
+    assert np.array_equal(slots_to_sources(g, arg), arg_ref.numpy())
+    assert arg.dtype == torch.uint8
+
+
+@pytest.mark.parametrize("f", [1, 3, 4, 8, 20, 64, 100, 256, 260, 512])
+@pytest.mark.parametrize("integer", [False, True])
+def test_max_forward_random_bit_exact(f, integer):
+    n = 300
+    src, dst = random_coo(n, 2000, seed=f)
+    dst[dst == 7] = 8                     # node 7: zero in-degree
+    tg, g = ref_and_gts(src, dst, n)
+    x = _feat(n, f, seed=f + 1, integer=integer)
+    out_ref, arg_ref = torch_ref.spmm_max_with_arg(tg, x)
+    out, arg = ops.spmm_max_fwd(g.to(DEV), x.to(DEV))
+    assert torch.equal(out.cpu(), out_ref)
+    assert np.array_equal(slots_to_sources(g, arg), arg_ref.numpy())
+    assert torch.all(out[7] == 0)
+    out_only, none = ops.spmm_max_fwd(g.to(DEV), x.to(DEV), want_arg=False)
+    assert none is None and torch.equal(out_only, out)
+
+
+def test_max_inf_and_high_degree_int32_arg():
+    n = 40
+    hub_src = np.arange(n).repeat(8)              # node 0 gets 320 in-edges -> int32 slots
+    hub_dst = np.zeros(n * 8, dtype=np.int64)
+    src, dst = random_coo(n, 100, seed=4)
+    src, dst = np.concatenate([hub_src, src]), np.concatenate([hub_dst, dst])
+    tg, g = ref_and_gts(src, dst, n)
+    assert g.arg_bytes == 4
+    x = _feat(n, 12, seed=5)
+    x[3, 2] = float("inf"); x[4, 5] = float("-inf")
+    out_ref, arg_ref = torch_ref.spmm_max_with_arg(tg, x)
+    out, arg = ops.spmm_max_fwd(g.to(DEV), x.to(DEV))
+    assert arg.dtype == torch.int32
+    assert torch.equal(out.cpu(), out_ref)
+    assert np.array_equal(slots_to_sources(g, arg), arg_ref.numpy())
+    assert out[0, 2] == 0                         # +inf maximum is replaced by 0 (R-max)
+
+
+@pytest.mark.parametrize("f", [3, 4, 20, 256, 512])
+def test_max_backward_matches_oracle(f):
+    n = 200
+    src, dst = random_coo(n, 1500, seed=100 + f)
+    tg, g = ref_and_gts(src, dst, n)
+    gd = g.to(DEV)
+    x = _feat(n, f, seed=f, integer=True)         # integer data: ties everywhere
+    gout = _feat(n, f, seed=f + 9, integer=True)  # integer grads: sums are exact in any order
+    xr = x.clone().requires_grad_(True)
+    torch_ref.spmm_max(tg, xr).backward(gout)
+    xd = x.to(DEV).requires_grad_(True)
+    ops.spmm_max(gd, xd).backward(gout.to(DEV))
+    assert torch.equal(xd.grad.cpu(), xr.grad)
+    # fused ReLU mask: gradient zeroed where the (ReLU-ed) source is <= 0
+    out, arg = ops.spmm_max_fwd(gd, x.to(DEV))
+    masked = ops.spmm_max_bwd(gd, gout.to(DEV), arg, relu_src=x.to(DEV))
+    assert torch.equal(masked.cpu(), xr.grad * (x > 0))
+
+
+# ------------------------------------------------------------------ K3 / K4
+@pytest.mark.parametrize("mode", ["sum", "mean", "gcn"])
+@pytest.mark.parametrize("f", [1, 4, 8, 20, 256, 300])
+def test_sum_family_forward_backward_bit_exact(mode, f):
+    n = 257
+    src, dst = random_coo(n, 1800, seed=f)
+    dst[dst == 5] = 6
+    tg, g = ref_and_gts(src, dst, n)
+    ref_fn = {"sum": torch_ref.spmm_sum, "mean": torch_ref.spmm_mean, "gcn": torch_ref.spmm_gcn}[mode]
+    x = _feat(n, f, seed=f + 3)
+    gout = _feat(n, f, seed=f + 4)
+    xr = x.clone().requires_grad_(True)
+    yr = ref_fn(tg, xr)
+    yr.backward(gout)
+    xd = x.to(DEV).requires_grad_(True)
+    yd = ops.spmm_reduce(g.to(DEV), xd, mode)
+    yd.backward(gout.to(DEV))
+    assert torch.equal(yd.detach().cpu(), yr.detach()), "forward differs"
+    assert torch.equal(xd.grad.cpu(), xr.grad), "backward differs"
+
+
+def test_sum_order_sensitivity_case():
+    src = np.array([0, 1, 2]); dst = np.array([3, 3, 3])
+    _, g = ref_and_gts(src, dst, 4)
+    x = torch.tensor([[1e8], [1.0], [-1e8], [0.0]])
+    assert ops.spmm_reduce(g.to(DEV), x.to(DEV), "sum")[3, 0].item() == 0.0
+
+
+# ------------------------------------------------------------------ K5-K8
+@pytest.mark.parametrize("heads,dim", [(1, 4), (2, 3), (4, 16), (3, 64), (4, 256), (2, 320)])
+def test_gat_aggregate_matches_oracle(heads, dim):
+    n = 150
+    src, dst = random_coo(n, 700, seed=heads * 1000 + dim, min_in_degree=1)
+    tg, g = ref_and_gts(src, dst, n)
+    gen = torch.Generator().manual_seed(dim)
+    ft = torch.randn(n, heads, dim, generator=gen)
+    el = torch.randn(n, heads, generator=gen)
+    er = torch.randn(n, heads, generator=gen)
+    gout = torch.randn(n, heads, dim, generator=gen)
+    r = [t.clone().requires_grad_(True) for t in (ft, el, er)]
+    out_ref, a_ref = torch_ref.gat_aggregate(tg, r[0], r[1], r[2], 0.2)
+    out_ref.backward(gout)
+    d = [t.to(DEV).requires_grad_(True) for t in (ft, el, er)]
+    out = ops.gat_aggregate(g.to(DEV), d[0], d[1], d[2], 0.2)
+    out.backward(gout.to(DEV))
+    tol = dict(rtol=1e-5, atol=1e-5)
+    assert torch.allclose(out.detach().cpu(), out_ref.detach(), **tol)
+    for got, want, name in zip(d, r, ("ft", "el", "er")):
+        assert torch.allclose(got.grad.cpu(), want.grad, rtol=1e-4, atol=2e-5), name
+
+
+# ------------------------------------------------------------------ K12
+def test_projection_matches_reference_fixture(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "ref_project.npz"))
+    svs = torch.from_numpy(fx["svs"]).to(DEV)
+    lab = ops.project_rows(svs, torch.from_numpy(fx["labels"]).to(DEV), torch.zeros(1, dtype=torch.int64, device=DEV))
+    assert lab.dtype == torch.int64 and np.array_equal(lab.cpu().numpy(), fx["out_labels"])
+    logit = ops.project_rows(svs, torch.from_numpy(fx["logits"]).to(DEV),
+                             torch.tensor(fx["background"][0], dtype=torch.float32, device=DEV))
+    assert np.array_equal(logit.cpu().numpy().astype(np.float64), fx["out_logits"])
+    # the drop-in wrappers (numpy in -> numpy out, reference dtypes)
+    from data_processing import graph_io
+    out = graph_io.project_nodes_to_img(fx["svs"], fx["labels"])
+    assert out.dtype == fx["out_labels"].dtype and np.array_equal(out, fx["out_labels"])
+    out = graph_io.project_node_logits_to_img(fx["svs"], fx["logits"], fx["background"].tolist())
+    assert out.dtype == np.float64 and np.array_equal(out, fx["out_logits"])
+
+
+@pytest.mark.parametrize("shape", [(1,), (7,), (513,), (33, 17, 9), (64, 64, 40)])
+def test_projection_ragged_sizes_bit_exact(shape):
+    rng = np.random.default_rng(sum(shape))
+    n_nodes = 1000
+    svs = rng.integers(-1, n_nodes, size=shape).astype(np.int16)
+    labels = rng.integers(0, 4, size=n_nodes).astype(np.int64)
+    logits = rng.standard_normal((n_nodes, 4)).astype(np.float32)
+    sv = torch.from_numpy(svs).to(DEV)
+    got = ops.project_rows(sv, torch.from_numpy(labels).to(DEV), torch.zeros(1, dtype=torch.int64, device=DEV))
+    assert np.array_equal(got.cpu().numpy(), graph_ref.project_nodes_to_img_ref(svs, labels))
+    got = ops.project_rows(sv, torch.from_numpy(logits).to(DEV), torch.tensor([1.0, -1, -1, -1], device=DEV))
+    assert np.array_equal(got.cpu().numpy().astype(np.float64), graph_ref.project_logits_to_img_ref(svs, logits))
+    relabel = torch.tensor([0, 2, 1, 4], dtype=torch.int16, device=DEV)
+    pred = ops.project_argmax(sv, torch.from_numpy(logits).to(DEV), relabel).cpu().numpy()
+    node_pred = torch.max(torch.from_numpy(logits), dim=1)[1].numpy()
+    want = graph_ref.swap_labels_to_brats_ref(graph_ref.project_nodes_to_img_ref(svs, node_pred))
+    assert pred.dtype == np.int16 and np.array_equal(pred, want)
+
+
+def test_projection_unaligned_view_and_empty():
+    base = torch.randint(-1, 50, (1001,), dtype=torch.int16, device=DEV)
+    table = torch.arange(50, dtype=torch.int64, device=DEV) * 3
+    bg = torch.tensor([-7], dtype=torch.int64, device=DEV)
+    view = base[1:].contiguous()              # fresh allocation; still exercises odd length
+    got = ops.project_rows(view, table, bg).cpu().numpy()
+    want = np.append(table.cpu().numpy(), -7)[view.cpu().numpy()]
+    assert np.array_equal(got, want)
+    assert ops.project_rows(base[:0], table, bg).numel() == 0
+
+
+# ------------------------------------------------------------------ full-size properties (C2 / C5)
+def test_full_size_max_properties_c2():
+    """N_b = 60 000, F = 256 (4 lattice graphs): checked against torch's own GPU reducers."""
+    g = gts.batch([synth.lattice_graph() for _ in range(4)]).to(DEV)
+    assert g.n == 60000 and g.number_of_edges() == 4 * 86350
+    x = torch.randn(g.n, 256, device=DEV)
+    out, arg = ops.spmm_max_fwd(g, x)
+    d = g.dev()
+    dst = torch.repeat_interleave(torch.arange(g.n, device=DEV), (d.indptr[1:] - d.indptr[:-1]).long())
+    want = torch.full_like(x, float("-inf")).scatter_reduce(
+        0, dst[:, None].expand(-1, 256), x[d.indices.long()], "amax", include_self=True)
+    assert torch.equal(out, want)                           # bit-exact maximum
+    pos = d.indptr[:-1].long()[:, None] + arg.long()         # argmax consistency: x[arg] == out
+    assert torch.equal(x[d.indices.long()[pos], torch.arange(256, device=DEV)[None, :]], out)
+    # idempotence of the reducer on a constant field and linearity of the sum reducer
+    ones = torch.ones(g.n, 256, device=DEV)
+    assert torch.equal(ops.spmm_max_fwd(g, ones, want_arg=False)[0], ones)
+    deg = (d.indptr[1:] - d.indptr[:-1]).float()[:, None]
+    assert torch.equal(ops.spmm_sum_raw(g, ones), deg.expand(-1, 256))
+    y = torch.randn(g.n, 256, device=DEV)
+    lhs = ops.spmm_sum_raw(g, x + y)
+    rhs = ops.spmm_sum_raw(g, x) + ops.spmm_sum_raw(g, y)
+    assert torch.allclose(lhs, rhs, rtol=1e-5, atol=1e-5)
+    # backward conserves mass: every gout element lands on exactly one source
+    gout = torch.rand(g.n, 256, device=DEV)
+    gx = ops.spmm_max_bwd(g, gout, arg)
+    assert torch.allclose(gx.sum(0), gout.sum(0), rtol=1e-4)
+
+
+def test_full_size_projection_c5():
+    vol = synth.supervoxel_volume((240, 240, 240), cube=10, shell=20)
+    logits = torch.randn(15000, 4, device=DEV)
+    sv = torch.from_numpy(vol).to(DEV)
+    out = ops.project_rows(sv, logits, torch.tensor([1.0, -1, -1, -1], device=DEV))
+    assert out.shape == (240, 240, 240, 4)
+    table = torch.cat([logits, torch.tensor([[1.0, -1, -1, -1]], device=DEV)])
+    assert torch.equal(out, table[sv.long()])
+    assert torch.equal(out[0, 0, 0], torch.tensor([1.0, -1, -1, -1], device=DEV))
