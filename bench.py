@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training throughput (supervoxel-graphs/sec) of 7xGraphSAGE-pool-256
+on synthetic 15k-node supervoxel graphs, N MI355X GPUs (BASELINE.json metric, config C2).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + class-weighted cross-entropy + backward + (gradient all-reduce when
+N > 1) + AdamW update on one batch of `--graphs-per-gpu` (default 4) 15 000-node lattice
+graphs per GPU (N_b = 60 000 nodes, E_b = 345 400 edges), in_feats 4, fp32, layer_sizes
+[256]*7 => 8 SAGEConv layers.  Inputs are resident in HBM before the timed region.  Weak
+scaling: per-GPU work is fixed, global batch = graphs-per-gpu x N.
+
+Rank 0 prints ONE JSON line with the throughput, plus
+  "roofline":     achieved algorithmic bandwidth of the dominant aggregation kernel
+                  (spmm_max_fwd, F=256, with argmax) from HIP events around every launch of
+                  it inside the timed region, against the 8 TB/s HBM peak;
+  "cpu_baseline": the CPU oracle (pure-PyTorch restatement of the DGL CPU path) timed on this
+                  box's host cores on a bounded sample of the same workload (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "gnn-tumor-seg_amd")
+for _p in (REPO, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak BW (spec)
+LAYER_SIZES = [256] * 7
+IN_FEATS = 4
+N_CLASSES = 4
+CLASS_WEIGHTS = [0.1, 1.0, 2.0, 2.0]
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--graphs-per-gpu", type=int, default=4)
+    ap.add_argument("--graph-kind", default="lattice", choices=["lattice", "random"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP-event pairs around every launch of one kernel on torch's current stream (the
+    stream gts launches on)."""
+
+    def __init__(self):
+        self.pairs = []
+        self.enabled = False
+
+    def __call__(self, launch):
+        if not self.enabled:
+            return launch()
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = launch()
+        b.record()
+        self.pairs.append((a, b))
+        return out
+
+    def mean_ms(self):
+        return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else None
+
+
+def build_batches(rank, graphs_per_gpu, kind, n_batches, device):
+    """Distinct synthetic batches for this rank, uploaded once (graph g uses seed 1000+g)."""
+    import gts
+    from gts import synth
+
+    batches = []
+    for b in range(n_batches):
+        first = (rank * n_batches + b) * graphs_per_gpu
+        samples = [synth.make_sample(first + i, kind=kind, in_feats=IN_FEATS) for i in range(graphs_per_gpu)]
+        g = gts.batch([s[1] for s in samples]).to(device)
+        g.dev()  # upload CSR now, not inside the timed region
+        feats = torch.from_numpy(np.concatenate([s[2] for s in samples])).to(device)
+        labels = torch.from_numpy(np.concatenate([s[3] for s in samples])).to(device)
+        batches.append((g, feats, labels))
+    return batches
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Cores this process may actually use: CPU affinity, capped by the cgroup CPU quota."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def cpu_baseline(graphs_per_gpu, kind, steps):
+    """Oracle training step on the host cores, same workload, bounded sample."""
+    from collections import namedtuple
+
+    from gts import synth
+    from oracle import graph_ref, torch_ref
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} host cores (os.cpu_count()={os.cpu_count()})")
+    HP = namedtuple("HP", "in_feats out_classes layer_sizes gat_heads gat_residuals")
+    torch.manual_seed(0)
+    net = torch_ref.ref_init_graph_net("GSpool", HP(IN_FEATS, N_CLASSES, LAYER_SIZES, None, None))
+    opt = torch_ref.make_optimizer(net)
+    samples = [synth.make_sample(i, kind=kind, in_feats=IN_FEATS) for i in range(graphs_per_gpu)]
+    ref = graph_ref.batch_ref([graph_ref.RefGraph(s[1].src, s[1].dst, s[1].n) for s in samples])
+    tg = torch_ref.TGraph(ref)
+    feats = torch.from_numpy(np.concatenate([s[2] for s in samples]))
+    labels = torch.from_numpy(np.concatenate([s[3] for s in samples]))
+    w = torch.tensor(CLASS_WEIGHTS)
+    t0 = time.perf_counter()
+    torch_ref.train_step(net, tg, feats, labels, w, opt)      # warm-up
+    log(f"cpu warm-up step {time.perf_counter() - t0:.1f} s")
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        torch_ref.train_step(net, tg, feats, labels, w, opt)
+        log(f"cpu step done at +{time.perf_counter() - t0:.1f} s")
+    dt = time.perf_counter() - t0
+    return {"value": graphs_per_gpu * steps / dt, "unit": "graphs/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} training steps (+1 warm-up) of the same batch of {graphs_per_gpu} "
+                      f"15k-node {kind} graphs, 8 SAGEConv-pool-256 layers, fp32, torch CPU oracle"}
+
+
+def main():
+    args = parse_args()
+    from gts import dist as gdist
+
+    rank, world, local_rank = gdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs MI355X GPUs (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from gts import _lib, ops
+    from model.gnn_model import GNN
+    from utils.hyperparam_helpers import FullParamSet
+
+    _lib.load()
+    hp = FullParamSet(1, IN_FEATS, N_CLASSES, 1e-4, 0.98, 1e-4, CLASS_WEIGHTS, LAYER_SIZES, 0, None, None)
+    torch.manual_seed(0)
+    model = GNN("GSpool", hp, None)
+    if world > 1:
+        for p in model.net.parameters():
+            torch.distributed.broadcast(p.data, src=0)
+        model.grad_sync = gdist.FlatGradSync(model.net.parameters())
+    model.net.train()
+    batches = build_batches(rank, args.graphs_per_gpu, args.graph_kind, n_batches=2, device=device)
+    n_b, e_b = batches[0][0].n, batches[0][0].number_of_edges()
+
+    timer = KernelTimer()
+    ops.DOMINANT_KERNEL_TIMER = timer
+
+    def step(i):
+        g, feats, labels = batches[i % len(batches)]
+        return model.train_step(g, feats, labels)
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    log(f"rank {rank}/{world}: batches resident (N_b={n_b}, E_b={e_b}); warm-up")
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    log("timed region")
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
+    global_batch = args.graphs_per_gpu * world
+    value = global_batch * args.steps / elapsed
+
+    if rank == 0:
+        f = 256
+        arg_bytes = batches[0][0].arg_bytes
+        # algorithmic bytes of ONE spmm_max_fwd launch at F=256: one source row
+        # per edge + output row + argmax slots + int32 indices/indptr
+        alg_bytes = 4 * f * e_b + 4 * f * n_b + arg_bytes * f * n_b + 4 * (e_b + n_b + 1)
+        ms = timer.mean_ms()
+        achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms else None
+        traffic = None
+        pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as fh:
+                traffic = json.load(fh).get("spmm_max_fwd_f256_bytes_per_launch")
+        result = {
+            "metric": "supervoxel-graphs/sec training, 7xSAGE-pool-256, 15k-node graphs",
+            "value": round(value, 3), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C2: 7xGraphSAGE-pool-256 (8 SAGEConv), fwd+weighted-CE+bwd+AdamW, "
+                                   f"{args.graphs_per_gpu} x 15k-node/{e_b // args.graphs_per_gpu}-edge "
+                                   f"{args.graph_kind} graphs per GPU, 4-chan feat, fp32",
+                       "global_batch": global_batch, "nodes_per_batch": n_b, "edges_per_batch": e_b,
+                       "parallelism": f"dp{world}", "final_loss": round(float(loss), 6)},
+            "roofline": {"bound": "hbm", "kernel": "spmm_max_fwd_kernel<4,64,1> (F=256, uint8 argmax)",
+                         "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_us": round(ms * 1e3, 2) if ms else None,
+                         "launches_timed": len(timer.pairs)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.graphs_per_gpu, args.graph_kind, args.cpu_steps)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

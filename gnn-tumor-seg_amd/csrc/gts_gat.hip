@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
       den += expf(leaky(el[static_cast<size_t>(indices[k]) * heads + h] + er_v, slope) - m);
     den = group_sum<LPR>(den);
     // pass 2: weights + weighted gather
-    for (int c = gl * VEC; c < dim; c += LPR * VEC) {
+    for_columns<VEC, LPR>(dim, [&](int c, bool active) {
       float acc[VEC];
 #pragma unroll
       for (int t = 0; t < VEC; ++t) acc[t] = 0.0f;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
         for (int j = 0; j < CNT; ++j) {
           if (src.valid(j)) {
             a[j] = expf(leaky(a[j] + er_v, slope) - m) / den;
-            if (c == 0 && gl == 0) attn[static_cast<size_t>(k + j) * heads + h] = a[j];
+            if (active && c == 0) attn[static_cast<size_t>(k + j) * heads + h] = a[j];
 #pragma unroll
             for (int t = 0; t < VEC; ++t) acc[t] += a[j] * val[j].v[t];
           }
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
       Vec<VEC> o;
 #pragma unroll
       for (int t = 0; t < VEC; ++t) o.v[t] = acc[t];
-      o.store(out + static_cast<size_t>(r) * dim + c);
-    }
+      if (active) o.store(out + static_cast<size_t>(r) * dim + c);
+    });
   }
 }
 
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_kernel(
       for (int k = beg; k < end; ++k) acc += ge[static_cast<size_t>(t_pos[k]) * heads + h];
       gel[r] = acc;
     }
-    for (int c = gl * VEC; c < dim; c += LPR * VEC) {
+    for_columns<VEC, LPR>(dim, [&](int c, bool active) {
       float acc[VEC];
 #pragma unroll
       for (int t = 0; t < VEC; ++t) acc[t] = 0.0f;
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_kernel(
       Vec<VEC> o;
 #pragma unroll
       for (int t = 0; t < VEC; ++t) o.v[t] = acc[t];
-      o.store(gft + static_cast<size_t>(r) * dim + c);
-    }
+      if (active) o.store(gft + static_cast<size_t>(r) * dim + c);
+    });
   }
 }
 

@@ -21,6 +21,20 @@ __device__ __forceinline__ int owned_row(int s, int seq, int n_rows) {
   return v < n_rows ? v : -1;
 }
 
+// Column walk of one row.  The trip count is the same for every lane (wave-uniform for
+// LPR == 64, where the chunk code below broadcasts indices with v_readlane and therefore
+// needs all 64 lanes alive); a lane whose columns lie past the end runs on column 0 and
+// must not store (`active` false).
+template <int VEC, int LPR, typename Body>
+__device__ __forceinline__ void for_columns(int n_feat, Body&& body) {
+  const int gl = (threadIdx.x & (kWave - 1)) % LPR;
+  for (int c0 = 0; c0 < n_feat; c0 += LPR * VEC) {
+    const int c = c0 + gl * VEC;
+    const bool active = c < n_feat;
+    body(active ? c : 0, active);
+  }
+}
+
 // Neighbour chunks.  A row's in-edges are consumed in chunks of <= kUnroll so that all of a
 // chunk's row loads are in flight together.  Every chunk body is straight-line code:
 //  * LPR == 64 (row is wave-uniform): the exact count is a template parameter (switch on

