@@ -29,7 +29,12 @@ SIGNATURES = {
     "gts_gat_bwd_src_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     "gts_project_rows_i16": [_p, _p, _p, _p, _i64, _i64, _i32, _p],
     "gts_project_argmax_i16": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
+    "gts_linear_fwd_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p],
+    "gts_linear_bwd_input_f32": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
+    "gts_linear_bwd_weight_workspace": [_i64, _i64, _i64],
+    "gts_linear_bwd_weight_f32": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
 }
+_RESTYPE = {"gts_error_string": ctypes.c_char_p, "gts_linear_bwd_weight_workspace": _i64}
 
 _lib = None
 
@@ -58,7 +63,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError -> the .so is stale; surface it
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == "gts_error_string" else _i32
+        fn.restype = _RESTYPE.get(name, _i32)
     if lib.gts_abi_version() != ABI_VERSION:
         raise GtsError(f"libgts_hip.so ABI {lib.gts_abi_version()} != expected {ABI_VERSION}: rebuild")
     _lib = lib

@@ -1,40 +1,130 @@
-"""Dense layer GEMMs of the GNN path (K11): out = act(a0 @ w0^T [+ a1 @ w1^T] + bias).
+"""Dense layer GEMMs of the GNN path (K11) on the MI355X matrix cores.
 
-Single seam for the dense work inside SAGEConv / GATConv so that the fused layer ops in
-gts.nn never touch a GEMM API directly.  fp32 throughout (the reference trains in fp32).
+Single seam for the dense work inside SAGEConv / GATConv: every function calls the
+hand-written fp32 MFMA kernels of libgts_hip.so (gts_linear_*), never a BLAS library.
+fp32 throughout (the reference trains in fp32; gfx950 has no TF32-like shortcut).
+
+Shape rule of the kernels: every dimension that indexes a contiguous axis must be a multiple
+of 4 (16-byte loads).  Feature widths of the reference (4, 20, 256, class count 4) satisfy
+it; anything else is zero-padded here, on the host side of the ABI.
 """
 import torch
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import check, current_stream, ptr, require_device
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    """Caller-owned scratch for the split-reduction weight gradient (grown on demand, reused:
+    kernels on one stream run in order, so one buffer per device is enough)."""
+    buf = _workspaces.get(device)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _workspaces[device] = buf
+    return buf
+
+
+def _pad4_cols(t):
+    """Zero-pad the last dim of a 2-D tensor to a multiple of 4 (no copy when aligned)."""
+    pad = (-t.shape[1]) % 4
+    return t.contiguous() if pad == 0 else F.pad(t, (0, pad)).contiguous()
+
+
+def _pad4_rows(t):
+    pad = (-t.shape[0]) % 4
+    return t.contiguous() if pad == 0 else F.pad(t, (0, 0, 0, pad)).contiguous()
+
+
+def _chk(*tensors):
+    for t in tensors:
+        if t is not None and t.dtype != torch.float32:
+            raise _lib.GtsError(f"gts GEMMs are fp32: got {t.dtype}")
+    return require_device(*tensors)
 
 
 def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False):
-    """a0 [M,K0], w0 [N,K0] (torch Linear layout), optional second operand pair."""
-    if bias is not None:
-        out = torch.addmm(bias, a0, w0.t())
-    else:
-        out = torch.mm(a0, w0.t())
+    """out = act(a0 @ w0^T [+ a1 @ w1^T] + bias).  a [M,K], w [N,K] (torch Linear layout)."""
+    a0, w0 = _pad4_cols(a0), _pad4_cols(w0)
     if a1 is not None:
-        out.addmm_(a1, w1.t())
-    if relu:
-        out.relu_()
+        a1, w1 = _pad4_cols(a1), _pad4_cols(w1)
+    dev = _chk(a0, w0, a1, w1, bias)
+    m, n = a0.shape[0], w0.shape[0]
+    out = torch.empty((m, n), dtype=torch.float32, device=dev)
+    check(_lib.load().gts_linear_fwd_f32(ptr(a0), ptr(w0), ptr(a1), ptr(w1),
+                                         ptr(bias.contiguous()) if bias is not None else None, ptr(out),
+                                         m, n, a0.shape[1], a1.shape[1] if a1 is not None else 0,
+                                         1 if relu else 0, current_stream()), "gts_linear_fwd_f32")
     return out
 
 
-def linear_bwd_input(g, w, out=None):
-    """g [M,N], w [N,K] -> g @ w [M,K]; accumulates into `out` when given."""
-    if out is None:
-        return torch.mm(g, w)
-    return out.addmm_(g, w)
+def linear_bwd_input(g0, w0, g1=None, w1=None):
+    """g0 @ w0 [+ g1 @ w1].  g [M,N], w [N,K] -> [M,K]."""
+    k = w0.shape[1]
+    kp = k + (-k) % 4
+    g0, w0 = _pad4_cols(g0), _pad4_cols(_pad4_rows(w0))
+    if g1 is not None:
+        g1, w1 = _pad4_cols(g1), _pad4_cols(_pad4_rows(w1))
+    dev = _chk(g0, w0, g1, w1)
+    m = g0.shape[0]
+    gin = torch.empty((m, kp), dtype=torch.float32, device=dev)
+    check(_lib.load().gts_linear_bwd_input_f32(ptr(g0), ptr(w0), ptr(g1), ptr(w1), ptr(gin), m, kp,
+                                               g0.shape[1], g1.shape[1] if g1 is not None else 0,
+                                               current_stream()), "gts_linear_bwd_input_f32")
+    return gin if kp == k else gin[:, :k].contiguous()
 
 
-def linear_bwd_weight(g, a):
-    """g [M,N], a [M,K] -> g^T @ a [N,K]."""
-    return torch.mm(g.t(), a)
-
-
-def bias_grad(g):
-    return g.sum(dim=0)
+def linear_bwd_weight(g, a, want_bias_grad=False):
+    """(g^T @ a [N,K], column sums of g [N] or None).  g [M,N], a [M,K]."""
+    n, k = g.shape[1], a.shape[1]
+    g, a = _pad4_cols(g), _pad4_cols(a)
+    dev = _chk(g, a)
+    m, n_p, k_p = g.shape[0], g.shape[1], a.shape[1]
+    lib = _lib.load()
+    gw = torch.empty((n_p, k_p), dtype=torch.float32, device=dev)
+    gb = torch.empty(n_p, dtype=torch.float32, device=dev) if want_bias_grad else None
+    if m == 0:
+        gw.zero_()
+        if gb is not None:
+            gb.zero_()
+    else:
+        nbytes = lib.gts_linear_bwd_weight_workspace(m, n_p, k_p)
+        ws = _workspace(dev, nbytes)
+        check(lib.gts_linear_bwd_weight_f32(ptr(g), ptr(a), ptr(gw), ptr(gb), ptr(ws), ws.numel() * 4,
+                                            m, n_p, k_p, current_stream()), "gts_linear_bwd_weight_f32")
+    if (n_p, k_p) != (n, k):
+        gw = gw[:n, :k].contiguous()
+        gb = gb[:n].contiguous() if gb is not None else None
+    return gw, gb
 
 
 def relu_bwd(g, out):
     """g * (out > 0) where `out` is the ReLU output (new tensor; g is left untouched)."""
     return g * (out > 0)
+
+
+class _Linear(torch.autograd.Function):
+    """y = x @ w^T (+ bias): nn.Linear on the MFMA kernels (used by the non-fused layers)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return linear_fwd(x, w, bias=bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = linear_bwd_input(gy, w) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = linear_bwd_weight(gy, x, want_bias_grad=ctx.has_bias)
+        return gx, gw, gb if ctx.has_bias else None
+
+
+def linear(x, w, bias=None):
+    """Drop-in for F.linear on 2-D inputs."""
+    return _Linear.apply(x, w, bias)

@@ -45,17 +45,12 @@ class _SagePoolLayer(torch.autograd.Function):
         h, p, m, arg, out, w_pool, w_self, w_neigh = ctx.saved_tensors
         g = dense.relu_bwd(gout, out) if ctx.relu_out else gout.contiguous()
         need = ctx.needs_input_grad
-        g_bias = dense.bias_grad(g) if need[6] else None
-        g_ws = dense.linear_bwd_weight(g, h) if need[4] else None
-        g_wn = dense.linear_bwd_weight(g, m) if need[5] else None
+        g_ws, g_bias = dense.linear_bwd_weight(g, h, want_bias_grad=True)
+        g_wn, _ = dense.linear_bwd_weight(g, m)
         gm = dense.linear_bwd_input(g, w_neigh)
         gp = ops.spmm_max_bwd(ctx.g, gm, arg, relu_src=p)      # fused ReLU'(p)
-        g_bp = dense.bias_grad(gp) if need[3] else None
-        g_wp = dense.linear_bwd_weight(gp, h) if need[2] else None
-        gh = None
-        if need[1]:
-            gh = dense.linear_bwd_input(g, w_self)
-            gh = dense.linear_bwd_input(gp, w_pool, out=gh)
+        g_wp, g_bp = dense.linear_bwd_weight(gp, h, want_bias_grad=True)
+        gh = dense.linear_bwd_input(g, w_self, gp, w_pool) if need[1] else None   # one K=2N pass
         return None, gh, g_wp, g_bp, g_ws, g_wn, g_bias, None, None
 
 
@@ -115,11 +110,11 @@ class SAGEConv(nn.Module):
                                        fused_relu, need_bwd)
         else:
             lin_before_mp = self._in_src_feats > self._out_feats
-            src = self.fc_neigh(h) if lin_before_mp else h
+            src = dense.linear(h, self.fc_neigh.weight) if lin_before_mp else h
             neigh = ops.spmm_reduce(graph, src, self._aggre_type)
             if not lin_before_mp:
-                neigh = self.fc_neigh(neigh)
-            rst = neigh if self._aggre_type == "gcn" else self.fc_self(h) + neigh
+                neigh = dense.linear(neigh, self.fc_neigh.weight)
+            rst = neigh if self._aggre_type == "gcn" else dense.linear(h, self.fc_self.weight) + neigh
             if self.bias is not None:
                 rst = rst + self.bias
             if fused_relu:
@@ -181,12 +176,13 @@ class GATConv(nn.Module):
                                       "model/networks.py:77-78 passes no dropout to GAT)")
         n = feat.shape[0]
         h = self.feat_drop(feat)
-        ft = self.fc(h).view(n, self._num_heads, self._out_feats)
+        ft = dense.linear(h, self.fc.weight).view(n, self._num_heads, self._out_feats)
         el = (ft * self.attn_l).sum(dim=-1)
         er = (ft * self.attn_r).sum(dim=-1)
         rst = ops.gat_aggregate(graph, ft, el, er, self.negative_slope)
         if self.res_fc is not None:
-            rst = rst + self.res_fc(h).view(n, -1, self._out_feats)
+            res = dense.linear(h, self.res_fc.weight) if isinstance(self.res_fc, nn.Linear) else h
+            rst = rst + res.view(n, -1, self._out_feats)
         if self.bias is not None:
             rst = rst + self.bias.view(1, self._num_heads, self._out_feats)
         if self.activation is not None:

@@ -114,6 +114,31 @@ int32_t gts_project_argmax_i16(const int16_t* svs, const float* logits, const in
                                int16_t* out, int64_t n_vox, int64_t n_rows, int64_t n_classes,
                                void* stream);
 
+/* ---- K11: dense fp32 layer GEMMs on the matrix cores -------------------------------------
+ * Replace the nn.Linear calls inside DGL's SAGEConv / GATConv (fc_pool, fc_self + fc_neigh,
+ * fc; reached from model/networks.py:25,28,30,46,52,56) and their autograd.  Exact fp32
+ * (v_mfma_f32_32x32x2_f32).  All dims that index a contiguous axis must be multiples of 4.
+ *
+ * forward:  out[m, n] = act( sum_k a0[m,k] w0[n,k] + (a1 ? sum_k a1[m,k] w1[n,k] : 0) + bias[n] )
+ *   a0 [M,K0], w0 [N,K0], a1 [M,K1], w1 [N,K1] row-major (torch Linear layout); bias optional;
+ *   relu != 0 applies max(., 0).  The pair form is fc_self(h) + fc_neigh(m) in one pass. */
+int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const float* a1, const float* w1,
+                           const float* bias, float* out, int64_t m, int64_t n, int64_t k0,
+                           int64_t k1, int32_t relu, void* stream);
+/* input gradient:  gin[m, k] = sum_n g0[m,n] w0[n,k] + (g1 ? sum_n g1[m,n] w1[n,k] : 0)
+ *   g0 [M,N0], w0 [N0,K], g1 [M,N1], w1 [N1,K]. */
+int32_t gts_linear_bwd_input_f32(const float* g0, const float* w0, const float* g1, const float* w1,
+                                 float* gin, int64_t m, int64_t k, int64_t n0, int64_t n1,
+                                 void* stream);
+/* weight gradient:  gw[n, k] = sum_m g[m,n] a[m,k];  gb[n] = sum_m g[m,n] (gb optional).
+ *   The reduction over the M nodes is split over workgroups into slabs in `workspace`
+ *   (>= gts_linear_bwd_weight_workspace(m,n,k) bytes, caller-owned scratch) that a second
+ *   kernel adds in a fixed order: bitwise reproducible, no float atomics. */
+int64_t gts_linear_bwd_weight_workspace(int64_t m, int64_t n, int64_t k);
+int32_t gts_linear_bwd_weight_f32(const float* g, const float* a, float* gw, float* gb,
+                                  float* workspace, int64_t workspace_bytes, int64_t m, int64_t n,
+                                  int64_t k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,102 @@
+"""K11 fp32 MFMA GEMMs against torch (fp64 reference on the CPU).  The MFMA result is an
+exact-fp32 fma chain in a permuted k order, so it agrees with a fp64 reference to fp32
+rounding: |err| <= 2e-6 * sum_k |a_k b_k| is asserted (observed ~1e-7)."""
+import pytest
+import torch
+
+from gts import dense
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib(hip_lib):
+    assert torch.cuda.is_available()
+    return hip_lib
+
+
+def _rand(*shape, seed):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def _check(got, want64, bound64):
+    err = (got.cpu().double() - want64).abs()
+    assert torch.all(err <= 2e-6 * bound64 + 1e-30), f"max err {err.max():.3e}, bound {bound64.max():.3e}"
+
+
+SHAPES = [(1, 4, 4), (37, 4, 8), (128, 256, 4), (129, 4, 256), (300, 256, 256), (1000, 20, 256),
+          (515, 256, 260), (64, 8, 4), (2049, 128, 64), (250, 300, 132)]
+
+
+@pytest.mark.parametrize("m,k,n", SHAPES)
+@pytest.mark.parametrize("dual,relu,bias", [(False, False, False), (True, True, True), (False, True, True)])
+def test_linear_forward(m, k, n, dual, relu, bias):
+    a0, w0 = _rand(m, k, seed=1), _rand(n, k, seed=2)
+    a1, w1 = (_rand(m, k + 4, seed=3), _rand(n, k + 4, seed=4)) if dual else (None, None)
+    b = _rand(n, seed=5) if bias else None
+    want = a0.double() @ w0.double().t()
+    bound = a0.double().abs() @ w0.double().abs().t()
+    if dual:
+        want += a1.double() @ w1.double().t()
+        bound += a1.double().abs() @ w1.double().abs().t()
+    if bias:
+        want += b.double()
+        bound += b.double().abs()
+    if relu:
+        want = want.clamp(min=0)
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    got = dense.linear_fwd(dev(a0), dev(w0), dev(a1), dev(w1), bias=dev(b), relu=relu)
+    assert got.shape == (m, n)
+    _check(got, want, bound)
+
+
+@pytest.mark.parametrize("m,k,n", SHAPES)
+@pytest.mark.parametrize("dual", [False, True])
+def test_linear_input_gradient(m, k, n, dual):
+    g0, w0 = _rand(m, n, seed=1), _rand(n, k, seed=2)
+    g1, w1 = (_rand(m, n + 8, seed=3), _rand(n + 8, k, seed=4)) if dual else (None, None)
+    want = g0.double() @ w0.double()
+    bound = g0.double().abs() @ w0.double().abs()
+    if dual:
+        want += g1.double() @ w1.double()
+        bound += g1.double().abs() @ w1.double().abs()
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    got = dense.linear_bwd_input(dev(g0), dev(w0), dev(g1), dev(w1))
+    assert got.shape == (m, k)
+    _check(got, want, bound)
+
+
+@pytest.mark.parametrize("m,k,n", SHAPES + [(60000, 256, 256), (60000, 4, 256), (60000, 256, 4)])
+def test_linear_weight_and_bias_gradient(m, k, n):
+    g, a = _rand(m, n, seed=1), _rand(m, k, seed=2)
+    gw, gb = dense.linear_bwd_weight(g.to(DEV), a.to(DEV), want_bias_grad=True)
+    assert gw.shape == (n, k) and gb.shape == (n,)
+    _check(gw, g.double().t() @ a.double(), g.double().abs().t() @ a.double().abs())
+    _check(gb, g.double().sum(0), g.double().abs().sum(0))
+    gw2, none = dense.linear_bwd_weight(g.to(DEV), a.to(DEV))
+    assert none is None and torch.equal(gw2, gw)          # bitwise reproducible (fixed-order slabs)
+
+
+def test_linear_autograd_matches_torch():
+    x = _rand(333, 20, seed=1).to(DEV).requires_grad_(True)
+    w = _rand(64, 20, seed=2).to(DEV).requires_grad_(True)
+    b = _rand(64, seed=3).to(DEV).requires_grad_(True)
+    gy = _rand(333, 64, seed=4).to(DEV)
+    dense.linear(x, w, b).backward(gy)
+    got = [t.grad.clone() for t in (x, w, b)]
+    for t in (x, w, b):
+        t.grad = None
+    torch.nn.functional.linear(x, w, b).backward(gy)
+    for a, t in zip(got, (x, w, b)):
+        assert torch.allclose(a, t.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_unaligned_width_is_padded_on_the_host():
+    a, w = _rand(50, 5, seed=1), _rand(7, 5, seed=2)
+    got = dense.linear_fwd(a.to(DEV), w.to(DEV))
+    assert got.shape == (50, 7)
+    assert torch.allclose(got.cpu(), a @ w.t(), rtol=1e-5, atol=1e-5)
+    gx = dense.linear_bwd_input(_rand(50, 7, seed=3).to(DEV), w.to(DEV))
+    assert gx.shape == (50, 5)
+    assert torch.allclose(gx.cpu(), _rand(50, 7, seed=3) @ w, rtol=1e-5, atol=1e-5)
