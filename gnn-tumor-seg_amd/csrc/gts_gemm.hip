@@ -6,16 +6,17 @@
 //     C[ra, rb] = sum_kk  A(ra, kk) * B(rb, kk)
 //   forward      out[M,N] = act[M,K] . W[N,K]^T (+ second pair) + bias, ReLU
 //                A = act  (kk contiguous),  B = W   (kk contiguous)
-//   input grad   gin[M,K] = g[M,N] . W[N,K]   (+ second pair)
+//   input grad   gin[M,K] = g[M,N] . W[N,K]   (+ second pair), optional ReLU mask on gin
 //                A = g    (kk contiguous),  B = W   (kk strided: B(k, n) = W[n*K + k])
 //   weight grad  gw[N,K]  = g[M,N]^T . act[M,K]   (reduction over the 60 000 nodes, split
 //                over blockIdx.z into per-split slabs that a second kernel sums in a fixed
-//                order -> bitwise reproducible, no float atomics)
+//                order -> bitwise reproducible, no float atomics); up to 4 same-shape
+//                problems share one launch (the three weight gradients of a SAGE layer);
 //                A = g    (kk strided: A(n, m) = g[m*N + n]),  B = act (kk strided)
 //                + the bias gradient (column sums of g) from the A fragments on the way.
 //
-// Tile: BM x BN outputs per 256-thread workgroup (2x2 waves, each (BM/2)x(BN/2) = TMxTN
-// 32x32 MFMA tiles), reduction in steps of 32.  Global -> registers (16 B/lane, issued one
+// Tile: BM x BN outputs per workgroup of WM x WN waves, each wave (BM/WM)x(BN/WN) = TMxTN
+// 32x32 MFMA tiles, reduction in steps of 32.  Global -> registers (16 B/lane, issued one
 // tile ahead, in flight under the MFMAs) -> LDS (ds_write_b128) -> fragments.  LDS images:
 //   kk-contiguous operand: [rows][36]  (32 + 4 pad floats: ds_read_b128 of 4 consecutive kk per
 //                          lane is conflict-free for any 16 rows distinct mod 16);
@@ -23,8 +24,6 @@
 // The reduction index consumed by MFMA step (g, j) on lane-half h is 8g + 4h + j for both
 // operands — a permutation of kk inside each 8-block, free for a sum, chosen so that the
 // contiguous operand needs ONE 16-byte LDS read per four MFMAs.
-// Two workgroups per CU (<= 256 VGPR, <= 56 KB LDS): while one waits at its barrier the
-// other keeps the matrix pipe busy.
 #include "gts_common.h"
 
 namespace gts {
@@ -33,43 +32,51 @@ namespace {
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int kBK = 32;        // reduction elements per LDS tile
-constexpr int kKcLd = kBK + 4; // padded row of a kk-contiguous LDS image
+constexpr int kBK = 32;         // reduction elements per LDS tile
+constexpr int kKcLd = kBK + 4;  // padded row of a kk-contiguous LDS image
+constexpr int kMaxProblems = 4;
 
 struct GemmArgs {
-  const float* a[2];
+  const float* a[2];    // forward / input grad: the two (a, b) reduction segments
   const float* b[2];
   int lda[2], ldb[2];
-  int kseg[2];          // reduction length of each (a, b) pair; kseg[1] = 0 when unused
+  int kseg[2];          // reduction length of each segment; kseg[1] = 0 when unused
   int ra, rb;           // output rows / cols
-  float* c;             // [ra, rb] (or [splits][ra, rb] slabs)
+  float* c;             // [ra, rb]  (weight grad: slabs [problem][split][ra, rb])
   int ldc;
   const float* bias;    // [rb] or null
   int relu;
-  float* colsum;        // [splits][ra] column sums of the strided A operand, or null
+  const float* mask;    // [ra, rb] or null: output zeroed where mask <= 0 (fused ReLU backward)
+  // split-reduction (weight gradient) only
+  const float* pa[kMaxProblems];  // per-problem operands (same shapes)
+  const float* pb[kMaxProblems];
+  float* colsum;        // [problem][split][ra] column sums of A, or null
+  int n_problems;       // 0 -> plain GEMM
+  int tiles_n;          // output tiles along rb per problem
+  int n_splits;
   int tiles_per_split;  // reduction tiles handled by one blockIdx.z
 };
 
-template <int ROWS, bool KC>
+template <int ROWS, bool KC, int THREADS>
 struct OperandTile {
   static constexpr int kFloats = KC ? ROWS * kKcLd : kBK * ROWS;
-  static constexpr int kVec = ROWS * kBK / 4 / kBlock;  // float4 per thread per tile
-  static_assert(ROWS * kBK / 4 % kBlock == 0, "tile must divide over the workgroup");
+  static constexpr int kVec = ROWS * kBK / 4 / THREADS;  // float4 per thread per tile
+  static_assert(ROWS * kBK / 4 % THREADS == 0 && kVec >= 1, "tile must divide over the workgroup");
 
   // global -> registers.  `row0` first row of the tile, `k0` first reduction index.
   __device__ __forceinline__ static void load(v4f (&reg)[kVec], const float* __restrict__ p, int ld,
                                               int row0, int k0, int n_rows, int n_k) {
 #pragma unroll
     for (int q = 0; q < kVec; ++q) {
-      const int idx = threadIdx.x + kBlock * q;
+      const int idx = threadIdx.x + THREADS * q;
       int r, kk;
       if constexpr (KC) {
-        r = idx >> 3, kk = (idx & 7) * 4;            // 8 float4 per 32-wide row
+        r = idx >> 3, kk = (idx & 7) * 4;  // 8 float4 per 32-wide row
       } else {
         kk = idx / (ROWS / 4), r = (idx % (ROWS / 4)) * 4;
       }
       const int gr = row0 + r, gk = k0 + kk;
-      const bool ok = gr < n_rows && gk < n_k;        // dims are multiples of 4: all-or-nothing
+      const bool ok = gr < n_rows && gk < n_k;  // dims are multiples of 4: all-or-nothing
       const size_t off = KC ? static_cast<size_t>(gr) * ld + gk : static_cast<size_t>(gk) * ld + gr;
       reg[q] = ok ? *reinterpret_cast<const v4f*>(p + off) : v4f{0.f, 0.f, 0.f, 0.f};
     }
@@ -78,7 +85,7 @@ struct OperandTile {
   __device__ __forceinline__ static void store(const v4f (&reg)[kVec], float* lds) {
 #pragma unroll
     for (int q = 0; q < kVec; ++q) {
-      const int idx = threadIdx.x + kBlock * q;
+      const int idx = threadIdx.x + THREADS * q;
       int off;
       if constexpr (KC) {
         off = (idx >> 3) * kKcLd + (idx & 7) * 4;
@@ -103,19 +110,32 @@ struct OperandTile {
   }
 };
 
-template <int BM, int BN, bool AKC, bool BKC>
-__global__ __launch_bounds__(kBlock, 2) void gemm_kernel(const GemmArgs p) {
-  using TA = OperandTile<BM, AKC>;
-  using TB = OperandTile<BN, BKC>;
-  constexpr int WTM = BM / 2, WTN = BN / 2;      // wave tile
+// waves per SIMD to plan registers for: two co-resident workgroups when the accumulators allow
+constexpr int min_waves_per_simd(int wm, int wn, int tm, int tn) {
+  const int per_block = wm * wn / 4;                       // waves per SIMD of one workgroup
+  return per_block * ((tm * tn * 16 <= 64 || per_block == 1) ? 2 : 1);
+}
+
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
+__global__ __launch_bounds__(64 * WM * WN, min_waves_per_simd(WM, WN, BM / WM / 32, BN / WN / 32))
+void gemm_kernel(const GemmArgs p) {
+  constexpr int THREADS = 64 * WM * WN;
+  using TA = OperandTile<BM, AKC, THREADS>;
+  using TB = OperandTile<BN, BKC, THREADS>;
+  constexpr int WTM = BM / WM, WTN = BN / WN;    // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;    // MFMA tiles per wave
+  static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
   __shared__ float lds[TA::kFloats + TB::kFloats];
   float* lds_a = lds;
   float* lds_b = lds + TA::kFloats;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int wm = wave / WN, wn = wave % WN;
+  const int problem = p.n_problems ? blockIdx.y / p.tiles_n : 0;
+  const int tile_n = p.n_problems ? blockIdx.y % p.tiles_n : blockIdx.y;
+  const int m0 = blockIdx.x * BM, n0 = tile_n * BN;
+  const float* a_seg[2] = {p.n_problems ? p.pa[problem] : p.a[0], p.a[1]};
+  const float* b_seg[2] = {p.n_problems ? p.pb[problem] : p.b[0], p.b[1]};
 
   const int nt0 = (p.kseg[0] + kBK - 1) / kBK;
   const int nt1 = (p.kseg[1] + kBK - 1) / kBK;
@@ -132,14 +152,14 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_kernel(const GemmArgs p) {
   float csum[TM];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) csum[tm] = 0.f;
-  const bool want_colsum = !AKC && p.colsum != nullptr && blockIdx.y == 0 && wn == 0;
+  const bool want_colsum = !AKC && p.colsum != nullptr && tile_n == 0 && wn == 0;
 
   v4f ra[TA::kVec], rb[TB::kVec];
   auto fetch = [&](int t) {
     const int s = t >= nt0 ? 1 : 0;
     const int k0 = (s ? t - nt0 : t) * kBK;
-    TA::load(ra, p.a[s], p.lda[s], m0, k0, p.ra, p.kseg[s]);
-    TB::load(rb, p.b[s], p.ldb[s], n0, k0, p.rb, p.kseg[s]);
+    TA::load(ra, a_seg[s], p.lda[s], m0, k0, p.ra, p.kseg[s]);
+    TB::load(rb, b_seg[s], p.ldb[s], n0, k0, p.rb, p.kseg[s]);
   };
 
   if (t_beg < t_end) {
@@ -180,7 +200,8 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_kernel(const GemmArgs p) {
 
   // epilogue: C/D layout of the 32x32 MFMA — col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int i = lane & 31, h = lane >> 5;
-  float* c = p.c + static_cast<size_t>(blockIdx.z) * p.ra * p.ldc;
+  const size_t slab = p.n_problems ? static_cast<size_t>(problem) * p.n_splits + blockIdx.z : 0;
+  float* c = p.c + slab * p.ra * p.ldc;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int col = n0 + wn * WTN + tn * 32 + i;
@@ -190,9 +211,13 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * WTM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        float val = acc[tm][tn][r] + bias;
-        if (p.relu) val = fmaxf(val, 0.f);
-        if (row < p.ra && col < p.rb) c[static_cast<size_t>(row) * p.ldc + col] = val;
+        if (row < p.ra && col < p.rb) {
+          const size_t off = static_cast<size_t>(row) * p.ldc + col;
+          float val = acc[tm][tn][r] + bias;
+          if (p.relu) val = fmaxf(val, 0.f);
+          if (p.mask != nullptr) val = p.mask[off] > 0.f ? val : 0.f;
+          c[off] = val;
+        }
       }
     }
   }
@@ -201,46 +226,115 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_kernel(const GemmArgs p) {
     for (int tm = 0; tm < TM; ++tm) {
       const float total = csum[tm] + __shfl_xor(csum[tm], 32, kWave);  // the two kk halves
       const int row = m0 + wm * WTM + tm * 32 + i;
-      if (h == 0 && row < p.ra) p.colsum[static_cast<size_t>(blockIdx.z) * p.ra + row] = total;
+      if (h == 0 && row < p.ra) p.colsum[slab * p.ra + row] = total;
     }
   }
 }
 
-// out[i] = sum_s slab[s][i] in split order (deterministic); float4 granularity when n % 4 == 0
-__global__ __launch_bounds__(kBlock) void reduce_slabs_kernel(const float* __restrict__ slabs,
-                                                             float* __restrict__ out, int64_t n,
-                                                             int splits) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i >= n) return;
-  float acc = 0.f;
-  for (int s = 0; s < splits; ++s) acc += slabs[static_cast<size_t>(s) * n + i];
-  out[i] = acc;
+// out_q[i] = sum_s slab[q][s][i] for problems q, summed in split order inside four interleaved
+// split groups whose partials are then added in group order: a fixed association, so results
+// are bitwise reproducible.  One float4 column per thread-quad.
+struct ReduceArgs {
+  const float* slabs;
+  float* out[kMaxProblems];
+  int64_t n4;  // float4 per problem
+  int splits;
+};
+
+__global__ __launch_bounds__(kBlock) void reduce_slabs_kernel(const ReduceArgs p) {
+  __shared__ v4f part[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 64 + col;
+  const int q = blockIdx.y;
+  v4f acc = {0.f, 0.f, 0.f, 0.f};
+  if (i < p.n4) {
+    const v4f* src = reinterpret_cast<const v4f*>(p.slabs) + static_cast<size_t>(q) * p.splits * p.n4 + i;
+    for (int s = grp; s < p.splits; s += 4) acc += src[static_cast<size_t>(s) * p.n4];
+  }
+  part[grp][col] = acc;
+  __syncthreads();
+  if (grp == 0 && i < p.n4) {
+    const v4f total = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+    reinterpret_cast<v4f*>(p.out[q])[i] = total;
+  }
 }
 
 inline bool aligned4(int64_t x) { return (x & 3) == 0; }
 
-template <bool AKC, bool BKC>
-int launch_gemm(const GemmArgs& p, int splits, hipStream_t st, bool square_tile = false) {
-  // BN = 256 when the output is wide enough to fill it, else the narrowest tile that covers rb;
-  // the split-reduction GEMM uses 128x128 tiles (more output tiles -> fewer, smaller slabs)
-  if (square_tile && p.rb > 64) {
-    dim3 grid((p.ra + 127) / 128, (p.rb + 127) / 128, splits);
-    gemm_kernel<128, 128, AKC, BKC><<<grid, kBlock, 0, st>>>(p);
-  } else if (p.rb > 128) {
-    dim3 grid((p.ra + 127) / 128, (p.rb + 255) / 256, splits);
-    gemm_kernel<128, 256, AKC, BKC><<<grid, kBlock, 0, st>>>(p);
-  } else if (p.rb > 64) {
-    dim3 grid((p.ra + 127) / 128, 1, splits);
-    gemm_kernel<128, 128, AKC, BKC><<<grid, kBlock, 0, st>>>(p);
-  } else {
-    dim3 grid((p.ra + 127) / 128, 1, splits);
-    gemm_kernel<128, 64, AKC, BKC><<<grid, kBlock, 0, st>>>(p);
-  }
+// Tile configurations (runtime-selectable for tuning through gts_set_option).
+// Defaults from tools/tune_gemm.py at M = 60 000, 256-wide (profiles/r01_tune_gemm.log).
+int g_fwd_variant = 0;     // forward kernels (both operands kk-contiguous)
+int g_igrad_variant = 1;   // input-gradient kernels (B kk-strided)
+int g_wgrad_variant = -1;  // split-reduction kernel; -1 = 2 when problems are batched, else 1
+
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
+int launch_tiles(const GemmArgs& p, int grid_y_mult, int splits, hipStream_t st) {
+  GemmArgs q = p;
+  q.tiles_n = (p.rb + BN - 1) / BN;
+  dim3 grid((p.ra + BM - 1) / BM, q.tiles_n * grid_y_mult, splits);
+  gemm_kernel<BM, BN, WM, WN, AKC, BKC><<<grid, 64 * WM * WN, 0, st>>>(q);
   return launch_status();
+}
+
+template <bool AKC, bool BKC>
+int launch_plain(const GemmArgs& p, hipStream_t st) {
+  if (p.rb <= 64) return launch_tiles<128, 64, 2, 2, AKC, BKC>(p, 1, 1, st);
+  if (p.rb <= 128) return launch_tiles<128, 128, 2, 2, AKC, BKC>(p, 1, 1, st);
+  switch (BKC ? g_fwd_variant : g_igrad_variant) {
+    case 1: return launch_tiles<128, 256, 2, 4, AKC, BKC>(p, 1, 1, st);
+    case 2: return launch_tiles<64, 256, 1, 4, AKC, BKC>(p, 1, 1, st);
+    case 3: return launch_tiles<64, 256, 2, 4, AKC, BKC>(p, 1, 1, st);
+    case 4: return launch_tiles<128, 128, 2, 2, AKC, BKC>(p, 1, 1, st);
+    case 5: return launch_tiles<256, 128, 4, 2, AKC, BKC>(p, 1, 1, st);
+    default: return launch_tiles<128, 256, 2, 2, AKC, BKC>(p, 1, 1, st);
+  }
+}
+
+// tile edge lengths of the split-reduction variants (needed to size the workspace)
+inline int wgrad_variant(int n_problems) {
+  return g_wgrad_variant >= 0 ? g_wgrad_variant : (n_problems > 1 ? 2 : 1);
+}
+
+inline void wgrad_tile(int64_t k, int n_problems, int* bm, int* bn) {
+  const int v = wgrad_variant(n_problems);
+  *bm = 128;
+  *bn = k <= 64 ? 64 : 128;
+  if (k > 64 && v == 2) *bn = 256;
+  if (k > 64 && v == 3) *bm = 64, *bn = 256;
+}
+
+inline int wgrad_splits(int64_t m, int64_t n, int64_t k, int n_problems) {
+  int bm, bn;
+  wgrad_tile(k, n_problems, &bm, &bn);
+  const int64_t tiles = (m + kBK - 1) / kBK;
+  const int64_t out_tiles = ((n + bm - 1) / bm) * ((k + bn - 1) / bn) * n_problems;
+  int64_t splits = (512 + out_tiles - 1) / out_tiles;  // ~2 workgroups per CU in flight
+  if (splits > tiles) splits = tiles;
+  return static_cast<int>(splits < 1 ? 1 : splits);
+}
+
+int launch_wgrad(const GemmArgs& p, int splits, hipStream_t st) {
+  const int np = p.n_problems;
+  if (p.rb <= 64) return launch_tiles<128, 64, 2, 2, false, false>(p, np, splits, st);
+  switch (wgrad_variant(np)) {
+    case 1: return launch_tiles<128, 128, 2, 4, false, false>(p, np, splits, st);
+    case 2: return launch_tiles<128, 256, 2, 4, false, false>(p, np, splits, st);
+    case 3: return launch_tiles<64, 256, 1, 4, false, false>(p, np, splits, st);
+    default: return launch_tiles<128, 128, 2, 2, false, false>(p, np, splits, st);
+  }
 }
 
 }  // namespace
 }  // namespace gts
+
+extern "C" int32_t gts_set_option(int32_t option, int32_t value) {
+  switch (option) {
+    case GTS_OPT_GEMM_TILE: gts::g_fwd_variant = value; return GTS_OK;
+    case GTS_OPT_IGRAD_TILE: gts::g_igrad_variant = value; return GTS_OK;
+    case GTS_OPT_WGRAD_TILE: gts::g_wgrad_variant = value; return GTS_OK;
+    default: return GTS_ERR_ARGKIND;
+  }
+}
 
 extern "C" int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const float* a1,
                                       const float* w1, const float* bias, float* out, int64_t m,
@@ -258,14 +352,15 @@ extern "C" int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const fl
   p.a[1] = a1 ? a1 : a0, p.b[1] = w1 ? w1 : w0;
   p.lda[1] = p.ldb[1] = static_cast<int>(k1), p.kseg[1] = a1 ? static_cast<int>(k1) : 0;
   p.ra = static_cast<int>(m), p.rb = static_cast<int>(n), p.c = out, p.ldc = static_cast<int>(n);
-  p.bias = bias, p.relu = relu, p.colsum = nullptr;
+  p.bias = bias, p.relu = relu;
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
-  return launch_gemm<true, true>(p, 1, static_cast<hipStream_t>(stream));
+  return launch_plain<true, true>(p, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int32_t gts_linear_bwd_input_f32(const float* g0, const float* w0, const float* g1,
-                                            const float* w1, float* gin, int64_t m, int64_t k,
-                                            int64_t n0, int64_t n1, void* stream) {
+                                            const float* w1, const float* relu_mask, float* gin,
+                                            int64_t m, int64_t k, int64_t n0, int64_t n1,
+                                            void* stream) {
   using namespace gts;
   if (!g0 || !w0 || !gin || ((g1 == nullptr) != (w1 == nullptr))) return GTS_ERR_NULL;
   if (m < 0 || k <= 0 || n0 <= 0 || n1 < 0 || m >= (1LL << 31) || k >= (1 << 20) ||
@@ -281,50 +376,64 @@ extern "C" int32_t gts_linear_bwd_input_f32(const float* g0, const float* w0, co
   p.lda[1] = static_cast<int>(n1), p.ldb[1] = static_cast<int>(k);
   p.kseg[1] = g1 ? static_cast<int>(n1) : 0;
   p.ra = static_cast<int>(m), p.rb = static_cast<int>(k), p.c = gin, p.ldc = static_cast<int>(k);
-  p.bias = nullptr, p.relu = 0, p.colsum = nullptr;
+  p.mask = relu_mask;
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
-  return launch_gemm<true, false>(p, 1, static_cast<hipStream_t>(stream));
+  return launch_plain<true, false>(p, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int64_t gts_linear_bwd_weight_workspace(int64_t m, int64_t n, int64_t k) {
+extern "C" int64_t gts_linear_bwd_weight_workspace(int64_t m, int64_t n, int64_t k,
+                                                   int32_t n_problems) {
   using namespace gts;
-  if (m <= 0 || n <= 0 || k <= 0) return 0;
-  const int64_t tiles = (m + kBK - 1) / kBK;
-  const int64_t out_tiles = ((n + 127) / 128) * ((k + 127) / 128);
-  int64_t splits = (512 + out_tiles - 1) / out_tiles;        // ~2 workgroups per CU in flight
-  if (splits > tiles) splits = tiles;
-  if (splits < 1) splits = 1;
-  return splits * (n * k + n) * static_cast<int64_t>(sizeof(float));
+  if (m <= 0 || n <= 0 || k <= 0 || n_problems < 1 || n_problems > kMaxProblems) return 0;
+  const int64_t splits = wgrad_splits(m, n, k, n_problems);
+  return n_problems * splits * (n * k + n) * static_cast<int64_t>(sizeof(float));
 }
 
-extern "C" int32_t gts_linear_bwd_weight_f32(const float* g, const float* a, float* gw, float* gb,
-                                             float* workspace, int64_t workspace_bytes, int64_t m,
-                                             int64_t n, int64_t k, void* stream) {
+extern "C" int32_t gts_linear_bwd_weight_f32(const float* const* g, const float* const* a,
+                                             float* const* gw, float* const* gb,
+                                             int32_t n_problems, float* workspace,
+                                             int64_t workspace_bytes, int64_t m, int64_t n,
+                                             int64_t k, void* stream) {
   using namespace gts;
   if (!g || !a || !gw || !workspace) return GTS_ERR_NULL;
+  if (n_problems < 1 || n_problems > kMaxProblems) return GTS_ERR_ARGKIND;
   if (m <= 0 || n <= 0 || k <= 0 || m >= (1LL << 31) || n >= (1 << 20) || k >= (1 << 20) ||
       !aligned4(n) || !aligned4(k))
     return GTS_ERR_SHAPE;
-  const int64_t need = gts_linear_bwd_weight_workspace(m, n, k);
-  if (workspace_bytes < need) return GTS_ERR_SHAPE;
-  const int splits = static_cast<int>(need / ((n * k + n) * static_cast<int64_t>(sizeof(float))));
+  if (workspace_bytes < gts_linear_bwd_weight_workspace(m, n, k, n_problems)) return GTS_ERR_SHAPE;
+  bool any_bias = false;
+  for (int q = 0; q < n_problems; ++q) {
+    if (!g[q] || !a[q] || !gw[q]) return GTS_ERR_NULL;
+    any_bias = any_bias || (gb && gb[q]);
+  }
+  const int splits = wgrad_splits(m, n, k, n_problems);
   const int tiles = static_cast<int>((m + kBK - 1) / kBK);
   hipStream_t st = static_cast<hipStream_t>(stream);
   GemmArgs p{};
   // C[n, k] = sum_m g[m, n] * act[m, k]: both operands reduction-strided
-  p.a[0] = g, p.b[0] = a, p.lda[0] = static_cast<int>(n), p.ldb[0] = static_cast<int>(k);
-  p.kseg[0] = static_cast<int>(m);
-  p.a[1] = g, p.b[1] = a, p.lda[1] = p.lda[0], p.ldb[1] = p.ldb[0], p.kseg[1] = 0;
+  for (int q = 0; q < n_problems; ++q) p.pa[q] = g[q], p.pb[q] = a[q];
+  p.a[0] = p.a[1] = g[0], p.b[0] = p.b[1] = a[0];
+  p.lda[0] = p.lda[1] = static_cast<int>(n), p.ldb[0] = p.ldb[1] = static_cast<int>(k);
+  p.kseg[0] = static_cast<int>(m), p.kseg[1] = 0;
   p.ra = static_cast<int>(n), p.rb = static_cast<int>(k);
   p.c = workspace, p.ldc = static_cast<int>(k);
-  p.bias = nullptr, p.relu = 0;
-  p.colsum = workspace + static_cast<size_t>(splits) * n * k;
+  p.colsum = any_bias ? workspace + static_cast<size_t>(n_problems) * splits * n * k : nullptr;
+  p.n_problems = n_problems, p.n_splits = splits;
   p.tiles_per_split = (tiles + splits - 1) / splits;
-  int rc = launch_gemm<false, false>(p, splits, st, /*square_tile=*/true);
+  int rc = launch_wgrad(p, splits, st);
   if (rc != GTS_OK) return rc;
-  const int64_t nk = n * k;
-  reduce_slabs_kernel<<<static_cast<unsigned>((nk + kBlock - 1) / kBlock), kBlock, 0, st>>>(workspace, gw, nk, splits);
-  if (gb != nullptr)
-    reduce_slabs_kernel<<<static_cast<unsigned>((n + kBlock - 1) / kBlock), kBlock, 0, st>>>(p.colsum, gb, n, splits);
+  ReduceArgs r{};
+  r.slabs = workspace, r.n4 = n * k / 4, r.splits = splits;
+  for (int q = 0; q < n_problems; ++q) r.out[q] = gw[q];
+  reduce_slabs_kernel<<<dim3(static_cast<unsigned>((r.n4 + 63) / 64), n_problems), kBlock, 0, st>>>(r);
+  if (any_bias) {
+    // bias slabs are contiguous per problem like the weight slabs; problems without a gb
+    // pointer still need a destination, so they reduce into the (dead) head of their own slab
+    ReduceArgs rb{};
+    rb.slabs = p.colsum, rb.n4 = n / 4, rb.splits = splits;
+    for (int q = 0; q < n_problems; ++q)
+      rb.out[q] = gb[q] ? gb[q] : workspace + (static_cast<size_t>(q) * splits) * n * k;
+    reduce_slabs_kernel<<<dim3(static_cast<unsigned>((rb.n4 + 63) / 64), n_problems), kBlock, 0, st>>>(rb);
+  }
   return launch_status();
 }

@@ -60,44 +60,64 @@ def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False):
     return out
 
 
-def linear_bwd_input(g0, w0, g1=None, w1=None):
-    """g0 @ w0 [+ g1 @ w1].  g [M,N], w [N,K] -> [M,K]."""
+def linear_bwd_input(g0, w0, g1=None, w1=None, relu_mask=None):
+    """g0 @ w0 [+ g1 @ w1].  g [M,N], w [N,K] -> [M,K]; zeroed where relu_mask [M,K] <= 0."""
     k = w0.shape[1]
     kp = k + (-k) % 4
     g0, w0 = _pad4_cols(g0), _pad4_cols(_pad4_rows(w0))
     if g1 is not None:
         g1, w1 = _pad4_cols(g1), _pad4_cols(_pad4_rows(w1))
-    dev = _chk(g0, w0, g1, w1)
+    if relu_mask is not None:
+        relu_mask = _pad4_cols(relu_mask)
+    dev = _chk(g0, w0, g1, w1, relu_mask)
     m = g0.shape[0]
     gin = torch.empty((m, kp), dtype=torch.float32, device=dev)
-    check(_lib.load().gts_linear_bwd_input_f32(ptr(g0), ptr(w0), ptr(g1), ptr(w1), ptr(gin), m, kp,
-                                               g0.shape[1], g1.shape[1] if g1 is not None else 0,
+    check(_lib.load().gts_linear_bwd_input_f32(ptr(g0), ptr(w0), ptr(g1), ptr(w1), ptr(relu_mask), ptr(gin),
+                                               m, kp, g0.shape[1], g1.shape[1] if g1 is not None else 0,
                                                current_stream()), "gts_linear_bwd_input_f32")
     return gin if kp == k else gin[:, :k].contiguous()
 
 
+def linear_bwd_weight_multi(problems):
+    """[(g [M,N], a [M,K], want_bias_grad), ...] (1..4 problems of ONE shape) ->
+    [(g^T @ a [N,K], column sums of g [N] or None), ...] in a single split-reduction launch."""
+    import ctypes
+
+    n, k = problems[0][0].shape[1], problems[0][1].shape[1]
+    gs = [_pad4_cols(g) for g, _, _ in problems]
+    acts = [_pad4_cols(a) for _, a, _ in problems]
+    dev = _chk(*gs, *acts)
+    m, n_p, k_p = gs[0].shape[0], gs[0].shape[1], acts[0].shape[1]
+    for g, a in zip(gs, acts):
+        if g.shape != (m, n_p) or a.shape != (m, k_p):
+            raise _lib.GtsError("batched weight gradients need identical shapes")
+    q = len(problems)
+    gws = [torch.empty((n_p, k_p), dtype=torch.float32, device=dev) for _ in range(q)]
+    gbs = [torch.empty(n_p, dtype=torch.float32, device=dev) if want else None for _, _, want in problems]
+    if m == 0:
+        for t in gws + [b for b in gbs if b is not None]:
+            t.zero_()
+    else:
+        lib = _lib.load()
+        nbytes = lib.gts_linear_bwd_weight_workspace(m, n_p, k_p, q)
+        ws = _workspace(dev, nbytes)
+        arr = ctypes.c_void_p * q
+        check(lib.gts_linear_bwd_weight_f32(arr(*[ptr(t) for t in gs]), arr(*[ptr(t) for t in acts]),
+                                            arr(*[ptr(t) for t in gws]), arr(*[ptr(t) for t in gbs]), q,
+                                            ptr(ws), ws.numel() * 4, m, n_p, k_p, current_stream()),
+              "gts_linear_bwd_weight_f32")
+    out = []
+    for gw, gb in zip(gws, gbs):
+        if (n_p, k_p) != (n, k):
+            gw = gw[:n, :k].contiguous()
+            gb = gb[:n].contiguous() if gb is not None else None
+        out.append((gw, gb))
+    return out
+
+
 def linear_bwd_weight(g, a, want_bias_grad=False):
     """(g^T @ a [N,K], column sums of g [N] or None).  g [M,N], a [M,K]."""
-    n, k = g.shape[1], a.shape[1]
-    g, a = _pad4_cols(g), _pad4_cols(a)
-    dev = _chk(g, a)
-    m, n_p, k_p = g.shape[0], g.shape[1], a.shape[1]
-    lib = _lib.load()
-    gw = torch.empty((n_p, k_p), dtype=torch.float32, device=dev)
-    gb = torch.empty(n_p, dtype=torch.float32, device=dev) if want_bias_grad else None
-    if m == 0:
-        gw.zero_()
-        if gb is not None:
-            gb.zero_()
-    else:
-        nbytes = lib.gts_linear_bwd_weight_workspace(m, n_p, k_p)
-        ws = _workspace(dev, nbytes)
-        check(lib.gts_linear_bwd_weight_f32(ptr(g), ptr(a), ptr(gw), ptr(gb), ptr(ws), ws.numel() * 4,
-                                            m, n_p, k_p, current_stream()), "gts_linear_bwd_weight_f32")
-    if (n_p, k_p) != (n, k):
-        gw = gw[:n, :k].contiguous()
-        gb = gb[:n].contiguous() if gb is not None else None
-    return gw, gb
+    return linear_bwd_weight_multi([(g, a, want_bias_grad)])[0]
 
 
 def relu_bwd(g, out):

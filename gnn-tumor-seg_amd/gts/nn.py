@@ -45,11 +45,14 @@ class _SagePoolLayer(torch.autograd.Function):
         h, p, m, arg, out, w_pool, w_self, w_neigh = ctx.saved_tensors
         g = dense.relu_bwd(gout, out) if ctx.relu_out else gout.contiguous()
         need = ctx.needs_input_grad
-        g_ws, g_bias = dense.linear_bwd_weight(g, h, want_bias_grad=True)
-        g_wn, _ = dense.linear_bwd_weight(g, m)
         gm = dense.linear_bwd_input(g, w_neigh)
         gp = ops.spmm_max_bwd(ctx.g, gm, arg, relu_src=p)      # fused ReLU'(p)
-        g_wp, g_bp = dense.linear_bwd_weight(gp, h, want_bias_grad=True)
+        if w_pool.shape == w_self.shape:                       # Fin == Fout: one launch for all three
+            (g_ws, g_bias), (g_wn, _), (g_wp, g_bp) = dense.linear_bwd_weight_multi(
+                [(g, h, True), (g, m, False), (gp, h, True)])
+        else:
+            (g_ws, g_bias), (g_wn, _) = dense.linear_bwd_weight_multi([(g, h, True), (g, m, False)])
+            g_wp, g_bp = dense.linear_bwd_weight(gp, h, want_bias_grad=True)
         gh = dense.linear_bwd_input(g, w_self, gp, w_pool) if need[1] else None   # one K=2N pass
         return None, gh, g_wp, g_bp, g_ws, g_wn, g_bias, None, None
 

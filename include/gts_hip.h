@@ -126,18 +126,30 @@ int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const float* a1, co
                            const float* bias, float* out, int64_t m, int64_t n, int64_t k0,
                            int64_t k1, int32_t relu, void* stream);
 /* input gradient:  gin[m, k] = sum_n g0[m,n] w0[n,k] + (g1 ? sum_n g1[m,n] w1[n,k] : 0)
- *   g0 [M,N0], w0 [N0,K], g1 [M,N1], w1 [N1,K]. */
+ *   g0 [M,N0], w0 [N0,K], g1 [M,N1], w1 [N1,K].  relu_mask (optional, [M,K]): gin is zeroed
+ *   where relu_mask <= 0, i.e. the ReLU backward of the layer that produced this input. */
 int32_t gts_linear_bwd_input_f32(const float* g0, const float* w0, const float* g1, const float* w1,
-                                 float* gin, int64_t m, int64_t k, int64_t n0, int64_t n1,
-                                 void* stream);
-/* weight gradient:  gw[n, k] = sum_m g[m,n] a[m,k];  gb[n] = sum_m g[m,n] (gb optional).
+                                 const float* relu_mask, float* gin, int64_t m, int64_t k,
+                                 int64_t n0, int64_t n1, void* stream);
+/* weight gradients of n_problems (1..4) same-shape problems in ONE launch (the three weight
+ * gradients of a SAGE layer):  gw[q][n, k] = sum_m g[q][m,n] a[q][m,k];
+ * gb[q][n] = sum_m g[q][m,n] where gb && gb[q].  g, a, gw, gb are HOST arrays of device pointers.
  *   The reduction over the M nodes is split over workgroups into slabs in `workspace`
- *   (>= gts_linear_bwd_weight_workspace(m,n,k) bytes, caller-owned scratch) that a second
- *   kernel adds in a fixed order: bitwise reproducible, no float atomics. */
-int64_t gts_linear_bwd_weight_workspace(int64_t m, int64_t n, int64_t k);
-int32_t gts_linear_bwd_weight_f32(const float* g, const float* a, float* gw, float* gb,
-                                  float* workspace, int64_t workspace_bytes, int64_t m, int64_t n,
-                                  int64_t k, void* stream);
+ *   (>= gts_linear_bwd_weight_workspace(m,n,k,n_problems) bytes, caller-owned scratch) that a
+ *   second kernel adds in a fixed order: bitwise reproducible, no float atomics. */
+int64_t gts_linear_bwd_weight_workspace(int64_t m, int64_t n, int64_t k, int32_t n_problems);
+int32_t gts_linear_bwd_weight_f32(const float* const* g, const float* const* a, float* const* gw,
+                                  float* const* gb, int32_t n_problems, float* workspace,
+                                  int64_t workspace_bytes, int64_t m, int64_t n, int64_t k,
+                                  void* stream);
+
+/* ---- tuning knobs -----------------------------------------------------------------------
+ * Process-wide tile selection of the K11 kernels (defaults are the tuned values; used by
+ * tools/tune_gemm.py).  Returns GTS_ERR_ARGKIND for an unknown option. */
+#define GTS_OPT_GEMM_TILE 1  /* forward tile variant */
+#define GTS_OPT_WGRAD_TILE 2 /* weight-gradient tile variant (-1 = automatic) */
+#define GTS_OPT_IGRAD_TILE 3 /* input-gradient tile variant */
+int32_t gts_set_option(int32_t option, int32_t value);
 
 #ifdef __cplusplus
 }
