@@ -244,3 +244,40 @@ def test_gnn_harness_trains_and_checkpoints(tmp_path):
     assert abs(float(loss) - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
     for (k, a), (_, b) in zip(model.net.state_dict().items(), ref.state_dict().items()):
         assert torch.allclose(a.cpu(), b, rtol=1e-4, atol=1e-6), k
+
+
+def test_rccl_world_size_one_flat_gradient_path():
+    """The data-parallel step on one rank over the real RCCL backend ('nccl' on ROCm): same
+    gradients and loss as the plain single-GPU step."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from gts import dist as gdist
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        hp = HP(4, 4, [64, 64], None, None)
+        _, mine = _net_pair("GSpool", hp, seed=7)
+        _, twin = _net_pair("GSpool", hp, seed=7)
+        src, dst = random_coo(500, 3000, seed=1)
+        g = gts.Graph(src, dst, 500).to(DEV)
+        x = torch.randn(500, 4, device=DEV)
+        y = torch.randint(0, 4, (500,), device=DEV)
+        w = torch.tensor([0.1, 1, 2, 2], device=DEV)
+        sync = gdist.FlatGradSync(mine.parameters())
+        sync.zero_grad()
+        sync.weighted_ce_backward(mine(g, x), y, w)
+        loss = sync.all_reduce_and_normalise()
+        ref_loss = F.cross_entropy(twin(g, x), y, weight=w)
+        ref_loss.backward()
+        assert abs(float(loss) - float(ref_loss)) < 1e-5 * abs(float(ref_loss))
+        for p, q in zip(mine.parameters(), twin.parameters()):
+            assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-6)
+    finally:
+        dist.destroy_process_group()
