@@ -134,8 +134,14 @@ void gemm_kernel(const GemmArgs p) {
   const int problem = p.n_problems ? blockIdx.y / p.tiles_n : 0;
   const int tile_n = p.n_problems ? blockIdx.y % p.tiles_n : blockIdx.y;
   const int m0 = blockIdx.x * BM, n0 = tile_n * BN;
-  const float* a_seg[2] = {p.n_problems ? p.pa[problem] : p.a[0], p.a[1]};
-  const float* b_seg[2] = {p.n_problems ? p.pb[problem] : p.b[0], p.b[1]};
+  // select with ternaries: a runtime index into the by-value argument struct would move the
+  // whole struct to scratch memory
+  const float* a_first = p.a[0];
+  const float* b_first = p.b[0];
+  if (p.n_problems) {
+    a_first = problem == 0 ? p.pa[0] : problem == 1 ? p.pa[1] : problem == 2 ? p.pa[2] : p.pa[3];
+    b_first = problem == 0 ? p.pb[0] : problem == 1 ? p.pb[1] : problem == 2 ? p.pb[2] : p.pb[3];
+  }
 
   const int nt0 = (p.kseg[0] + kBK - 1) / kBK;
   const int nt1 = (p.kseg[1] + kBK - 1) / kBK;
@@ -156,10 +162,12 @@ void gemm_kernel(const GemmArgs p) {
 
   v4f ra[TA::kVec], rb[TB::kVec];
   auto fetch = [&](int t) {
-    const int s = t >= nt0 ? 1 : 0;
-    const int k0 = (s ? t - nt0 : t) * kBK;
-    TA::load(ra, a_seg[s], p.lda[s], m0, k0, p.ra, p.kseg[s]);
-    TB::load(rb, b_seg[s], p.ldb[s], n0, k0, p.rb, p.kseg[s]);
+    const bool second = t >= nt0;
+    const int k0 = (second ? t - nt0 : t) * kBK;
+    TA::load(ra, second ? p.a[1] : a_first, second ? p.lda[1] : p.lda[0], m0, k0, p.ra,
+             second ? p.kseg[1] : p.kseg[0]);
+    TB::load(rb, second ? p.b[1] : b_first, second ? p.ldb[1] : p.ldb[0], n0, k0, p.rb,
+             second ? p.kseg[1] : p.kseg[0]);
   };
 
   if (t_beg < t_end) {
@@ -263,7 +271,7 @@ inline bool aligned4(int64_t x) { return (x & 3) == 0; }
 
 // Tile configurations (runtime-selectable for tuning through gts_set_option).
 // Defaults from tools/tune_gemm.py at M = 60 000, 256-wide (profiles/r01_tune_gemm.log).
-int g_fwd_variant = 0;     // forward kernels (both operands kk-contiguous)
+int g_fwd_variant = 3;     // forward kernels (both operands kk-contiguous)
 int g_igrad_variant = 1;   // input-gradient kernels (B kk-strided)
 int g_wgrad_variant = -1;  // split-reduction kernel; -1 = 2 when problems are batched, else 1
 

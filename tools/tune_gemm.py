@@ -41,12 +41,14 @@ def timeit(fn, flops, reps=30):
 g1 = 2.0 * M * F * F
 for v in range(6):
     lib.gts_set_option(1, v)
+    lib.gts_set_option(3, v)
     r = [timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), None, None, P(b), P(out), M, F, F, 0, 1, st), g1),
          timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), P(b), P(out), M, F, F, F, 1, st), 2 * g1),
          timeit(lambda: lib.gts_linear_bwd_input_f32(P(x), P(w), None, None, None, P(out), M, F, F, 0, st), g1),
          timeit(lambda: lib.gts_linear_bwd_input_f32(P(x), P(w), P(y), P(w2), P(x), P(out), M, F, F, F, st), 2 * g1)]
     print(f"fwd/igrad variant {v}: " + " | ".join(f"{us:7.1f} us {tf:6.1f} TF" for us, tf in r), flush=True)
-lib.gts_set_option(1, 0)
+lib.gts_set_option(1, 3)
+lib.gts_set_option(3, 1)
 arr1, arr3 = ctypes.c_void_p * 1, ctypes.c_void_p * 3
 for v in range(4):
     lib.gts_set_option(2, v)
@@ -56,6 +58,6 @@ for v in range(4):
                                                       arr3(*[P(t) for t in gw]), arr3(P(gb[0]), None, P(gb[2])), 3,
                                                       P(ws), ws.numel() * 4, M, F, F, st), 3 * g1)]
     print(f"wgrad variant {v}: " + " | ".join(f"{us:7.1f} us {tf:6.1f} TF" for us, tf in r), flush=True)
-lib.gts_set_option(2, 0)
+lib.gts_set_option(2, -1)
 t = timeit(lambda: torch.mm(x, w.t(), out=out) is None, g1)
 print(f"hipBLASLt mm (reference point): {t[0]:7.1f} us {t[1]:6.1f} TF")
