@@ -47,14 +47,87 @@ class _SagePoolLayer(torch.autograd.Function):
         need = ctx.needs_input_grad
         gm = dense.linear_bwd_input(g, w_neigh)
         gp = ops.spmm_max_bwd(ctx.g, gm, arg, relu_src=p)      # fused ReLU'(p)
-        if w_pool.shape == w_self.shape:                       # Fin == Fout: one launch for all three
-            (g_ws, g_bias), (g_wn, _), (g_wp, g_bp) = dense.linear_bwd_weight_multi(
-                [(g, h, True), (g, m, False), (gp, h, True)])
-        else:
-            (g_ws, g_bias), (g_wn, _) = dense.linear_bwd_weight_multi([(g, h, True), (g, m, False)])
-            g_wp, g_bp = dense.linear_bwd_weight(gp, h, want_bias_grad=True)
+        g_ws, g_wn, g_wp, g_bias, g_bp = _pool_layer_weight_grads(g, gp, h, m, w_pool, w_self)
         gh = dense.linear_bwd_input(g, w_self, gp, w_pool) if need[1] else None   # one K=2N pass
         return None, gh, g_wp, g_bp, g_ws, g_wn, g_bias, None, None
+
+
+def _pool_layer_weight_grads(g, gp, h, m, w_pool, w_self):
+    """(g_ws, g_wn, g_wp, g_bias, g_bp) of one pool layer; one launch when Fin == Fout."""
+    if w_pool.shape == w_self.shape:
+        (g_ws, g_bias), (g_wn, _), (g_wp, g_bp) = dense.linear_bwd_weight_multi(
+            [(g, h, True), (g, m, False), (gp, h, True)])
+    else:
+        (g_ws, g_bias), (g_wn, _) = dense.linear_bwd_weight_multi([(g, h, True), (g, m, False)])
+        g_wp, g_bp = dense.linear_bwd_weight(gp, h, want_bias_grad=True)
+    return g_ws, g_wn, g_wp, g_bias, g_bp
+
+
+class _SagePoolStack(torch.autograd.Function):
+    """A whole stack of SAGEConv('pool') layers (ReLU on all but the last) as ONE autograd node.
+
+    Same arithmetic as chaining `_SagePoolLayer`, but the ReLU backward of layer L-1 rides in the
+    epilogue of layer L's input-gradient GEMM (`relu_mask` = that layer's input, which IS layer
+    L-1's ReLU output), so no elementwise pass over [N, F] remains in the backward, and each
+    activation is stored once (layer L's input is layer L-1's output)."""
+
+    @staticmethod
+    def forward(ctx, g, x, need_bwd, *params):
+        n_layers = len(params) // 5
+        h = x.contiguous()
+        saved = []
+        for i in range(n_layers):
+            w_pool, b_pool, w_self, w_neigh, bias = params[5 * i:5 * i + 5]
+            last = i == n_layers - 1
+            p = dense.linear_fwd(h, w_pool, bias=b_pool, relu=True)
+            m, arg = ops.spmm_max_fwd(g, p, want_arg=need_bwd)
+            out = dense.linear_fwd(h, w_self, m, w_neigh, bias=bias, relu=not last)
+            saved += [h, p, m, arg]
+            h = out
+        if need_bwd:
+            ctx.g, ctx.n_layers = g, n_layers
+            ctx.save_for_backward(*saved, *params)
+        return h
+
+    @staticmethod
+    def backward(ctx, gout):
+        n = ctx.n_layers
+        tensors = ctx.saved_tensors
+        acts, params = tensors[:4 * n], tensors[4 * n:]
+        grads = [None] * (5 * n)
+        g = gout.contiguous()            # gradient w.r.t. the pre-activation output of layer i
+        gx = None
+        for i in reversed(range(n)):
+            h, p, m, arg = acts[4 * i:4 * i + 4]
+            w_pool, _b_pool, w_self, w_neigh, _bias = params[5 * i:5 * i + 5]
+            gm = dense.linear_bwd_input(g, w_neigh)
+            gp = ops.spmm_max_bwd(ctx.g, gm, arg, relu_src=p)
+            g_ws, g_wn, g_wp, g_bias, g_bp = _pool_layer_weight_grads(g, gp, h, m, w_pool, w_self)
+            grads[5 * i:5 * i + 5] = [g_wp, g_bp, g_ws, g_wn, g_bias]
+            if i > 0:      # h is layer i-1's ReLU output: its backward is the mask h > 0
+                g = dense.linear_bwd_input(g, w_self, gp, w_pool, relu_mask=h)
+            elif ctx.needs_input_grad[1]:
+                gx = dense.linear_bwd_input(g, w_self, gp, w_pool)
+        return (None, gx, None, *grads)
+
+
+def sage_pool_stack(graph, features, layers):
+    """Run `layers` (SAGEConv pool modules: ReLU on all but the last, no active dropout, bias on)
+    as one fused autograd node.  Returns None when the stack does not have that shape, so the
+    caller can fall back to the layer-by-layer path."""
+    for i, layer in enumerate(layers):
+        last = i == len(layers) - 1
+        if not isinstance(layer, SAGEConv) or layer._aggre_type != "pool" or layer.bias is None \
+                or layer.norm is not None or (layer.feat_drop.p > 0 and layer.training):
+            return None
+        if (layer.activation is not None) if last else (not _is_relu(layer.activation)):
+            return None
+    params = []
+    for layer in layers:
+        params += [layer.fc_pool.weight, layer.fc_pool.bias, layer.fc_self.weight,
+                   layer.fc_neigh.weight, layer.bias]
+    need_bwd = torch.is_grad_enabled() and (features.requires_grad or any(p.requires_grad for p in params))
+    return _SagePoolStack.apply(graph, features, need_bwd, *params)
 
 
 class SAGEConv(nn.Module):

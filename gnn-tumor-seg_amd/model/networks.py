@@ -8,7 +8,7 @@ modules registered under `layers.{i}` so checkpoints interchange (SURVEY.md §8b
 import torch.nn as nn
 import torch.nn.functional as F
 
-from gts.nn import GATConv, SAGEConv
+from gts.nn import GATConv, SAGEConv, sage_pool_stack
 
 _SAGE_AGGREGATORS = {"GSpool": "pool", "GSgcn": "gcn", "GSmean": "mean"}
 
@@ -24,8 +24,13 @@ class GraphSage(nn.Module):
                   for w_in, w_out in zip(widths[:-1], widths[1:])]
         head = SAGEConv(widths[-1], n_classes, aggregator_type, feat_drop=0, activation=None)
         self.layers = nn.ModuleList([*hidden, head])
+        self.fuse_layers = True
 
     def forward(self, graph, features):
+        # pool stacks run as one fused autograd node (identical arithmetic, see gts.nn)
+        fused = sage_pool_stack(graph, features, list(self.layers)) if self.fuse_layers else None
+        if fused is not None:
+            return fused
         h = features
         for conv in self.layers:
             h = conv(graph, h)

@@ -281,3 +281,31 @@ def test_rccl_world_size_one_flat_gradient_path():
             assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("hp", [HP(4, 4, [256] * 3, None, None), HP(20, 4, [64, 32], None, None)])
+def test_fused_pool_stack_equals_layer_by_layer_path(hp):
+    """The fused stack only moves the ReLU backward into a GEMM epilogue: bitwise identical."""
+    src, dst = random_coo(700, 4000, seed=3)
+    g = gts.Graph(src, dst, 700).to(DEV)
+    _, fused = _net_pair("GSpool", hp, seed=11)
+    _, plain = _net_pair("GSpool", hp, seed=11)
+    plain.fuse_layers = False
+    x = torch.randn(700, hp.in_feats, device=DEV)
+    y = torch.randint(0, 4, (700,), device=DEV)
+    outs = []
+    for net in (fused, plain):
+        xi = x.clone().requires_grad_(True)
+        logits = net(g, xi)
+        F.cross_entropy(logits, y).backward()
+        outs.append((logits.detach(), xi.grad, [p.grad for p in net.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)
+    with torch.no_grad():
+        assert torch.equal(fused(g, x), outs[0][0])          # inference path (no argmax written)
+    plain.layers[0].feat_drop.p = 0.5                          # active dropout -> stack declines
+    from gts.nn import sage_pool_stack
+    plain.train()
+    assert sage_pool_stack(g, x, list(plain.layers)) is None
