@@ -35,18 +35,20 @@ def init_from_env(backend=None):
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    if use_gpu:
+        # one GPU per rank; ranks wrap around only in single-GPU rehearsals (GTS_DIST_BACKEND=gloo)
+        local_rank = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
     if world_size > 1 and not dist.is_initialized():
-        use_gpu = torch.cuda.is_available()
-        if use_gpu:
-            torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = backend or os.environ.get("GTS_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
         kwargs = {}
-        if use_gpu:
+        if use_gpu and backend == "nccl":
             kwargs["device_id"] = torch.device("cuda", local_rank)
-        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank,
-                                world_size=world_size, **kwargs)
+        dist.init_process_group(backend, rank=rank, world_size=world_size, **kwargs)
     return rank, world_size, local_rank
 
 
