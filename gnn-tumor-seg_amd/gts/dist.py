@@ -89,8 +89,13 @@ class FlatGradSync:
 
     def weighted_ce_backward(self, logits, labels, class_weights):
         """Back-propagate the local numerator and stash (denominator, numerator)."""
-        num = F.cross_entropy(logits, labels, weight=class_weights, reduction="sum")
-        den = class_weights[labels].sum()
+        if logits.is_cuda:      # fused HIP pass: numerator (with gradient) + denominator at once
+            from . import ops
+            num, stats = ops.weighted_cross_entropy_stats(logits, labels, class_weights)
+            den = stats[1]
+        else:                   # CPU rehearsal (gloo tests drive this class with the oracle net)
+            num = F.cross_entropy(logits, labels, weight=class_weights, reduction="sum")
+            den = class_weights[labels].sum()
         num.backward()
         self.flat[self.n_grad] = den.detach()
         self.flat[self.n_grad + 1] = num.detach()

@@ -212,3 +212,50 @@ def project_argmax(svs, logits, relabel=None):
                                              logits.shape[0], logits.shape[1], current_stream()),
           "gts_project_argmax_i16")
     return out
+
+
+# ---------------------------------------------------------------- class-weighted cross-entropy
+class _WeightedCE(torch.autograd.Function):
+    """(logits [N,C], labels int64 [N], class_w [C] or None) -> stats = [num, den, num/den]."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, class_w):
+        logits, labels = logits.contiguous(), labels.contiguous()
+        _f32(logits, class_w)
+        require_device(logits, labels, class_w)
+        if labels.dtype != torch.int64 or labels.shape != logits.shape[:1]:
+            raise _lib.GtsError("labels must be int64 [N]")
+        n, c = logits.shape
+        lib = _lib.load()
+        ws = torch.empty(max(1, lib.gts_weighted_ce_workspace(n) // 4), dtype=torch.float32, device=logits.device)
+        grad = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        stats = torch.empty(3, dtype=torch.float32, device=logits.device)
+        check(lib.gts_weighted_ce_f32(ptr(logits), ptr(labels), ptr(class_w), ptr(grad), ptr(ws), ws.numel() * 4,
+                                      ptr(stats), n, c, current_stream()), "gts_weighted_ce_f32")
+        ctx.save_for_backward(grad, stats)
+        ctx.mark_non_differentiable(stats)
+        return stats[2].clone(), stats[0].clone(), stats
+
+    @staticmethod
+    def backward(ctx, g_mean, g_sum, _g_stats):
+        grad_unscaled, stats = ctx.saved_tensors
+        scale = g_sum + g_mean / stats[1]                # d(num)/dx = gu ; d(num/den)/dx = gu / den
+        return grad_unscaled * scale, None, None
+
+
+def weighted_cross_entropy(logits, labels, class_w=None, reduction="mean"):
+    """F.cross_entropy(logits, labels, weight=class_w, reduction=...) as one fused HIP pass.
+    'mean' is the weighted mean (sum_i w[y_i] nll_i / sum_i w[y_i]), 'sum' the numerator."""
+    mean, total, _ = _WeightedCE.apply(logits, labels, class_w)
+    if reduction == "mean":
+        return mean
+    if reduction == "sum":
+        return total
+    raise ValueError(reduction)
+
+
+def weighted_cross_entropy_stats(logits, labels, class_w=None):
+    """(numerator, [num, den, num/den]) — the numerator carries the gradient (used by the
+    data-parallel step, which normalises by the global denominator after the all-reduce)."""
+    _, total, stats = _WeightedCE.apply(logits, labels, class_w)
+    return total, stats

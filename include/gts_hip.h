@@ -143,6 +143,19 @@ int32_t gts_linear_bwd_weight_f32(const float* const* g, const float* const* a, 
                                   int64_t workspace_bytes, int64_t m, int64_t n, int64_t k,
                                   void* stream);
 
+/* ---- class-weighted cross-entropy ----------------------------------------------------------
+ * Replaces torch.nn.CrossEntropyLoss(weight=class_weights)(logits, labels) of the reference
+ * harness (model/gnn_model.py:30,42) and, through grad_unscaled, its backward.
+ *   out3 = { num = sum_i w[y_i] nll_i,  den = sum_i w[y_i],  num / den }
+ *   grad_unscaled[i,c] = w[y_i] (softmax(x_i)_c - [c == y_i])   (optional; d loss/dx = that / den)
+ * logits [n, n_classes] fp32, labels int64 in [0, n_classes) (no ignore_index), class_w optional.
+ * Deterministic two-level reduction through `workspace`
+ * (>= gts_weighted_ce_workspace(n) bytes).  n_classes <= 32. */
+int64_t gts_weighted_ce_workspace(int64_t n);
+int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const float* class_w,
+                            float* grad_unscaled, float* workspace, int64_t workspace_bytes,
+                            float* out3, int64_t n, int64_t n_classes, void* stream);
+
 /* ---- tuning knobs -----------------------------------------------------------------------
  * Process-wide tile selection of the K11 kernels (defaults are the tuned values; used by
  * tools/tune_gemm.py).  Returns GTS_ERR_ARGKIND for an unknown option. */

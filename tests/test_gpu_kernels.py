@@ -238,3 +238,27 @@ def test_full_size_projection_c5():
     table = torch.cat([logits, torch.tensor([[1.0, -1, -1, -1]], device=DEV)])
     assert torch.equal(out, table[sv.long()])
     assert torch.equal(out[0, 0, 0], torch.tensor([1.0, -1, -1, -1], device=DEV))
+
+
+# ------------------------------------------------------------------ weighted cross-entropy
+@pytest.mark.parametrize("n,c,weighted", [(1, 4, True), (1000, 4, True), (60000, 4, True), (777, 4, False),
+                                          (513, 7, True), (64, 1, True), (300, 32, True)])
+def test_weighted_cross_entropy_matches_torch(n, c, weighted):
+    import torch.nn.functional as F
+
+    gen = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, generator=gen) * 3
+    y = torch.randint(0, c, (n,), generator=gen)
+    w = (torch.rand(c, generator=gen) + 0.1) if weighted else None
+    x64 = x.double().requires_grad_(True)
+    for reduction in ("mean", "sum"):
+        want = F.cross_entropy(x64, y, weight=None if w is None else w.double(), reduction=reduction)
+        (gw,) = torch.autograd.grad(want, x64)
+        xd = x.to(DEV).requires_grad_(True)
+        got = ops.weighted_cross_entropy(xd, y.to(DEV), None if w is None else w.to(DEV), reduction=reduction)
+        (gg,) = torch.autograd.grad(got, xd)
+        assert abs(float(got) - float(want)) <= 2e-6 * max(1.0, abs(float(want)))
+        assert torch.allclose(gg.cpu().double(), gw, rtol=1e-5, atol=1e-7 * max(1.0, float(gw.abs().max())))
+    a = ops.weighted_cross_entropy(x.to(DEV), y.to(DEV), None if w is None else w.to(DEV))
+    b = ops.weighted_cross_entropy(x.to(DEV), y.to(DEV), None if w is None else w.to(DEV))
+    assert torch.equal(a, b)                      # deterministic reduction
