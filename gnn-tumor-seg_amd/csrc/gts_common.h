@@ -32,12 +32,24 @@ struct Vec<4> {
   __device__ __forceinline__ void store(float* p) const {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
+  // streaming variants: the line is not kept in L2 (write-once outputs / read-once inputs)
+  __device__ __forceinline__ void store_nt(float* p) const {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f4*>(p));
+  }
+  __device__ __forceinline__ static Vec load_nt(const float* p) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+    return Vec{{t[0], t[1], t[2], t[3]}};
+  }
 };
 template <>
 struct Vec<1> {
   float v[1];
   __device__ __forceinline__ static Vec load(const float* p) { return Vec{{*p}}; }
   __device__ __forceinline__ void store(float* p) const { *p = v[0]; }
+  __device__ __forceinline__ void store_nt(float* p) const { __builtin_nontemporal_store(v[0], p); }
+  __device__ __forceinline__ static Vec load_nt(const float* p) { return Vec{{__builtin_nontemporal_load(p)}}; }
 };
 
 inline int launch_status() {

@@ -24,7 +24,7 @@
 // The reduction index consumed by MFMA step (g, j) on lane-half h is 8g + 4h + j for both
 // operands — a permutation of kk inside each 8-block, free for a sum, chosen so that the
 // contiguous operand needs ONE 16-byte LDS read per four MFMAs.
-#include "gts_common.h"
+#include "gts_rows.h"
 
 namespace gts {
 namespace {
@@ -382,6 +382,8 @@ extern "C" int32_t gts_set_option(int32_t option, int32_t value) {
   switch (option) {
     case GTS_OPT_GEMM_TILE: gts::g_fwd_variant = value; return GTS_OK;
     case GTS_OPT_IGRAD_TILE: gts::g_igrad_variant = value; return GTS_OK;
+    case GTS_OPT_SPMM_ROWS_PER_WAVE: gts::g_spmm_seq = value; return GTS_OK;
+    case GTS_OPT_SPMM_STREAMING: gts::g_spmm_nt = value; return GTS_OK;
     case GTS_OPT_WGRAD_TILE: gts::g_wgrad_variant = value; return GTS_OK;
     default: return GTS_ERR_ARGKIND;
   }

@@ -95,7 +95,15 @@ struct Chunk {
 
 // rows each wave walks sequentially: enough tiles to fill 256 CUs several times over,
 // few enough that index prefetch amortises.
-inline int pick_seq(int64_t n_rows, int rows_per_wave_step) {
+// Tuning knobs (gts_set_option).  Defaults come from tools/tune_spmm.py on 4 x 15k-node lattice
+// graphs at F = 256 (profiles/r01_tune_spmm.log): K1 is fastest with 2 rows per wave and streaming
+// (non-temporal) stores of out/argmax; K2 with 1 row per wave and ordinary loads/stores.
+inline int g_spmm_seq = 0;   // rows per wave; 0 = the kernel's own default
+inline int g_spmm_nt = -1;   // streaming stores/loads of write-once / read-once rows; -1 = default
+
+inline int pick_seq(int64_t n_rows, int rows_per_wave_step, int preferred) {
+  if (g_spmm_seq > 0) return g_spmm_seq;
+  if (preferred > 0) return preferred;
   const int64_t steps = (n_rows + rows_per_wave_step - 1) / rows_per_wave_step;
   // aim for >= 8192 waves (256 CUs x 32) before lengthening the per-wave walk
   int seq = 1;
@@ -108,12 +116,12 @@ struct Geometry {
   dim3 grid;
 };
 
-inline Geometry make_geometry(int64_t n_rows, int64_t n_feat) {
+inline Geometry make_geometry(int64_t n_rows, int64_t n_feat, int preferred_seq = 0) {
   Geometry g;
   g.vec = (n_feat % 4 == 0) ? 4 : 1;
   g.lpr = lanes_per_row(n_feat / g.vec);
   const int rows_per_step = kWave / g.lpr;
-  g.seq = pick_seq(n_rows, rows_per_step);
+  g.seq = pick_seq(n_rows, rows_per_step, preferred_seq);
   const int64_t rows_per_block = static_cast<int64_t>(rows_per_step) * g.seq * kWavesPerBlock;
   g.grid = dim3(static_cast<unsigned>((n_rows + rows_per_block - 1) / rows_per_block));
   return g;

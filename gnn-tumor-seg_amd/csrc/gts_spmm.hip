@@ -78,7 +78,7 @@ template <int VEC, int LPR, int ARGB>
 __global__ __launch_bounds__(kBlock) void spmm_max_fwd_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const float* __restrict__ x, float* __restrict__ out, void* __restrict__ arg, int n_dst,
-    int n_feat, int seq) {
+    int n_feat, int seq, int nt) {
   for (int s = 0; s < seq; ++s) {
     const int v = owned_row<LPR>(s, seq, n_dst);
     if (v < 0) continue;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void spmm_max_fwd_kernel(
       }
       const size_t off = static_cast<size_t>(v) * n_feat + c;
       if (active) {
-        o.store(out + off);
+        if (nt) o.store_nt(out + off); else o.store(out + off);
         if constexpr (ARGB != 0) store_slots<VEC, ARGB>(arg, off, slot);
       }
     });
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void spmm_max_bwd_kernel(
     const int32_t* __restrict__ t_indptr, const int32_t* __restrict__ t_indices,
     const int32_t* __restrict__ t_slot, const float* __restrict__ gout,
     const void* __restrict__ arg, const float* __restrict__ relu_src, float* __restrict__ gx,
-    int n_src, int n_feat, int seq) {
+    int n_src, int n_feat, int seq, int nt) {
   for (int s = 0; s < seq; ++s) {
     const int u = owned_row<LPR>(s, seq, n_src);
     if (u < 0) continue;
@@ -162,14 +162,14 @@ __global__ __launch_bounds__(kBlock) void spmm_max_bwd_kernel(
       const size_t off = static_cast<size_t>(u) * n_feat + c;
       Vec<VEC> o;
       if (relu_src != nullptr) {
-        const Vec<VEC> p = Vec<VEC>::load(relu_src + off);
+        const Vec<VEC> p = nt ? Vec<VEC>::load_nt(relu_src + off) : Vec<VEC>::load(relu_src + off);
 #pragma unroll
         for (int t = 0; t < VEC; ++t) o.v[t] = p.v[t] > 0.0f ? acc[t] : 0.0f;
       } else {
 #pragma unroll
         for (int t = 0; t < VEC; ++t) o.v[t] = acc[t];
       }
-      if (active) o.store(gx + off);
+      if (active) { if (nt) o.store_nt(gx + off); else o.store(gx + off); }
     });
   }
 }
@@ -235,16 +235,17 @@ extern "C" int32_t gts_spmm_max_fwd_f32(const int32_t* indptr, const int32_t* in
   if (bad_shape(n_dst, n_feat)) return GTS_ERR_SHAPE;
   if (arg_bytes != 0 && arg_bytes != 1 && arg_bytes != 4) return GTS_ERR_ARGKIND;
   if (n_dst == 0) return GTS_OK;
-  const Geometry g = make_geometry(n_dst, n_feat);
+  const Geometry g = make_geometry(n_dst, n_feat, /*preferred_seq=*/2);
+  const int nt = g_spmm_nt < 0 ? 1 : g_spmm_nt;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nd = static_cast<int>(n_dst), nf = static_cast<int>(n_feat);
   GTS_DISPATCH_GEOM(g, {
     if (arg_bytes == 0)
-      spmm_max_fwd_kernel<VEC, LPR, 0><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, arg, nd, nf, g.seq);
+      spmm_max_fwd_kernel<VEC, LPR, 0><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, arg, nd, nf, g.seq, nt);
     else if (arg_bytes == 1)
-      spmm_max_fwd_kernel<VEC, LPR, 1><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, arg, nd, nf, g.seq);
+      spmm_max_fwd_kernel<VEC, LPR, 1><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, arg, nd, nf, g.seq, nt);
     else
-      spmm_max_fwd_kernel<VEC, LPR, 4><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, arg, nd, nf, g.seq);
+      spmm_max_fwd_kernel<VEC, LPR, 4><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, arg, nd, nf, g.seq, nt);
   })
   return launch_status();
 }
@@ -259,14 +260,15 @@ extern "C" int32_t gts_spmm_max_bwd_f32(const int32_t* t_indptr, const int32_t* 
   if (bad_shape(n_src, n_feat)) return GTS_ERR_SHAPE;
   if (arg_bytes != 1 && arg_bytes != 4) return GTS_ERR_ARGKIND;
   if (n_src == 0) return GTS_OK;
-  const Geometry g = make_geometry(n_src, n_feat);
+  const Geometry g = make_geometry(n_src, n_feat, /*preferred_seq=*/1);
+  const int nt = g_spmm_nt < 0 ? 0 : g_spmm_nt;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int ns = static_cast<int>(n_src), nf = static_cast<int>(n_feat);
   GTS_DISPATCH_GEOM(g, {
     if (arg_bytes == 1)
-      spmm_max_bwd_kernel<VEC, LPR, 1><<<g.grid, kBlock, 0, st>>>(t_indptr, t_indices, t_slot, gout, arg, relu_src, gx, ns, nf, g.seq);
+      spmm_max_bwd_kernel<VEC, LPR, 1><<<g.grid, kBlock, 0, st>>>(t_indptr, t_indices, t_slot, gout, arg, relu_src, gx, ns, nf, g.seq, nt);
     else
-      spmm_max_bwd_kernel<VEC, LPR, 4><<<g.grid, kBlock, 0, st>>>(t_indptr, t_indices, t_slot, gout, arg, relu_src, gx, ns, nf, g.seq);
+      spmm_max_bwd_kernel<VEC, LPR, 4><<<g.grid, kBlock, 0, st>>>(t_indptr, t_indices, t_slot, gout, arg, relu_src, gx, ns, nf, g.seq, nt);
   })
   return launch_status();
 }
