@@ -18,6 +18,10 @@ Rank 0 prints ONE JSON line with the throughput, plus
                   it inside the timed region, against the 8 TB/s HBM peak;
   "cpu_baseline": the CPU oracle (pure-PyTorch restatement of the DGL CPU path) timed on this
                   box's host cores on a bounded sample of the same workload (N=1 only).
+
+Other BASELINE.json configurations (parity-test cases, not the headline) can be timed with
+  --config c3   GAT 4 layers x 4 heads x 256 training on the same graphs   (graphs/s)
+  --config c5   batched no-grad forward + node->voxel logits projection to 240^3 (volumes/s)
 """
 import argparse
 import json
@@ -35,10 +39,20 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak BW (spec)
-LAYER_SIZES = [256] * 7
 IN_FEATS = 4
 N_CLASSES = 4
 CLASS_WEIGHTS = [0.1, 1.0, 2.0, 2.0]
+CONFIGS = {
+    "c2": dict(model="GSpool", layer_sizes=[256] * 7, heads=None, residuals=None,
+               metric="supervoxel-graphs/sec training, 7xSAGE-pool-256, 15k-node graphs",
+               kernel="spmm_max_fwd_f256"),
+    "c3": dict(model="GAT", layer_sizes=[256] * 4, heads=[4] * 4, residuals=[False] * 4,
+               metric="supervoxel-graphs/sec training, GAT 4 layers x 4 heads x 256, 15k-node graphs",
+               kernel="gat_fwd"),
+    "c5": dict(model="GSpool", layer_sizes=[256] * 7, heads=None, residuals=None,
+               metric="volumes/sec inference: 7xSAGE-pool-256 forward + node-logit->voxel projection to 240^3",
+               kernel="project_rows"),
+}
 
 
 def parse_args():
@@ -48,9 +62,14 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--graphs-per-gpu", type=int, default=4)
     ap.add_argument("--graph-kind", default="lattice", choices=["lattice", "random"])
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 class KernelTimer:
@@ -93,10 +112,6 @@ def build_batches(rank, graphs_per_gpu, kind, n_batches, device):
     return batches
 
 
-def log(msg):
-    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
-
-
 def host_cores():
     """Cores this process may actually use: CPU affinity, capped by the cgroup CPU quota."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -109,19 +124,23 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(graphs_per_gpu, kind, steps):
-    """Oracle training step on the host cores, same workload, bounded sample."""
-    from collections import namedtuple
+def hyperparams(cfg):
+    from utils.hyperparam_helpers import FullParamSet
 
+    return FullParamSet(1, IN_FEATS, N_CLASSES, 1e-4, 0.98, 1e-4, CLASS_WEIGHTS, cfg["layer_sizes"], 0,
+                        cfg["heads"], cfg["residuals"])
+
+
+def cpu_baseline(cfg, graphs_per_gpu, kind, steps):
+    """Oracle training step on the host cores, same workload, bounded sample."""
     from gts import synth
     from oracle import graph_ref, torch_ref
 
     cores = host_cores()
     torch.set_num_threads(cores)
     log(f"cpu baseline on {cores} host cores (os.cpu_count()={os.cpu_count()})")
-    HP = namedtuple("HP", "in_feats out_classes layer_sizes gat_heads gat_residuals")
     torch.manual_seed(0)
-    net = torch_ref.ref_init_graph_net("GSpool", HP(IN_FEATS, N_CLASSES, LAYER_SIZES, None, None))
+    net = torch_ref.ref_init_graph_net(cfg["model"], hyperparams(cfg))
     opt = torch_ref.make_optimizer(net)
     samples = [synth.make_sample(i, kind=kind, in_feats=IN_FEATS) for i in range(graphs_per_gpu)]
     ref = graph_ref.batch_ref([graph_ref.RefGraph(s[1].src, s[1].dst, s[1].n) for s in samples])
@@ -139,11 +158,24 @@ def cpu_baseline(graphs_per_gpu, kind, steps):
     dt = time.perf_counter() - t0
     return {"value": graphs_per_gpu * steps / dt, "unit": "graphs/s", "cores": cores, "kind": "port",
             "sample": f"{steps} training steps (+1 warm-up) of the same batch of {graphs_per_gpu} "
-                      f"15k-node {kind} graphs, 8 SAGEConv-pool-256 layers, fp32, torch CPU oracle"}
+                      f"15k-node {kind} graphs, {cfg['model']} {cfg['layer_sizes']}, fp32, torch CPU oracle"}
+
+
+def algorithmic_bytes(kernel, n_b, e_b, arg_bytes, heads=4, dim=256, n_vox=240 ** 3):
+    """Bytes one launch of the dominant kernel must move."""
+    f = 256
+    if kernel == "spmm_max_fwd_f256":   # source row per edge + out row + argmax slots + int32 CSR
+        return 4 * f * e_b + 4 * f * n_b + arg_bytes * f * n_b + 4 * (e_b + n_b + 1)
+    if kernel == "gat_fwd":             # ft slice per (edge, head) + out + attn + el/er + CSR
+        return 4 * heads * dim * e_b + 4 * heads * dim * n_b + 4 * heads * (3 * e_b + 2 * n_b) + 4 * (e_b + n_b + 1)
+    if kernel == "project_rows":        # int16 id in, 16-byte row out, per voxel
+        return (2 + 16) * n_vox
+    raise ValueError(kernel)
 
 
 def main():
     args = parse_args()
+    cfg = CONFIGS[args.config]
     from gts import dist as gdist
 
     rank, world, local_rank = gdist.init_from_env()
@@ -151,38 +183,50 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", torch.cuda.current_device())
 
-    from gts import _lib, ops
+    from gts import _lib, ops, synth
     from model.gnn_model import GNN
-    from utils.hyperparam_helpers import FullParamSet
 
     _lib.load()
-    hp = FullParamSet(1, IN_FEATS, N_CLASSES, 1e-4, 0.98, 1e-4, CLASS_WEIGHTS, LAYER_SIZES, 0, None, None)
     torch.manual_seed(0)
-    model = GNN("GSpool", hp, None)
+    model = GNN(cfg["model"], hyperparams(cfg), None)
     if world > 1:
         for p in model.net.parameters():
             torch.distributed.broadcast(p.data, src=0)
         model.grad_sync = gdist.FlatGradSync(model.net.parameters())
-    model.net.train()
     batches = build_batches(rank, args.graphs_per_gpu, args.graph_kind, n_batches=2, device=device)
     n_b, e_b = batches[0][0].n, batches[0][0].number_of_edges()
 
     timer = KernelTimer()
-    ops.DOMINANT_KERNEL_TIMER = timer
+    ops.KERNEL_TIMERS[cfg["kernel"]] = timer
 
-    def step(i):
-        g, feats, labels = batches[i % len(batches)]
-        return model.train_step(g, feats, labels)
+    if args.config == "c5":
+        model.net.eval()
+        svs = torch.from_numpy(synth.supervoxel_volume((240, 240, 240), cube=10, shell=20)).to(device)
+        bg = torch.tensor([1.0, -1.0, -1.0, -1.0], device=device)
+        per_graph = n_b // args.graphs_per_gpu
+
+        def step(i):
+            g, feats, _ = batches[i % len(batches)]
+            with torch.no_grad():
+                logits = model.net(g, feats)
+                vols = [ops.project_rows(svs, logits[k * per_graph:(k + 1) * per_graph], bg)
+                        for k in range(args.graphs_per_gpu)]
+            return vols[-1][0, 0, 0, 0]
+    else:
+        model.net.train()
+
+        def step(i):
+            g, feats, labels = batches[i % len(batches)]
+            return model.train_step(g, feats, labels)
 
     def fence():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    log(f"rank {rank}/{world}: batches resident (N_b={n_b}, E_b={e_b}); warm-up")
+    log(f"rank {rank}/{world}: {args.config} batches resident (N_b={n_b}, E_b={e_b}); warm-up")
     for i in range(args.warmup):
         step(i)
     fence()
@@ -190,7 +234,7 @@ def main():
     timer.enabled = True
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = step(i)
+        last = step(i)
     host_enqueue = time.perf_counter() - t0     # CPU time to enqueue K steps (no sync inside)
     fence()
     elapsed = time.perf_counter() - t0
@@ -205,39 +249,42 @@ def main():
     value = global_batch * args.steps / elapsed
 
     if rank == 0:
-        f = 256
-        arg_bytes = batches[0][0].arg_bytes
-        # algorithmic bytes of ONE spmm_max_fwd launch at F=256: one source row
-        # per edge + output row + argmax slots + int32 indices/indptr
-        alg_bytes = 4 * f * e_b + 4 * f * n_b + arg_bytes * f * n_b + 4 * (e_b + n_b + 1)
+        alg_bytes = algorithmic_bytes(cfg["kernel"], n_b, e_b, batches[0][0].arg_bytes)
         ms = timer.mean_ms()
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms else None
         traffic = None
         pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as fh:
-                traffic = json.load(fh).get("spmm_max_fwd_f256_bytes_per_launch")
+                traffic = json.load(fh).get(cfg["kernel"] + "_bytes_per_launch")
+        workloads = {
+            "c2": "C2: 7xGraphSAGE-pool-256 (8 SAGEConv), fwd+weighted-CE+bwd+AdamW",
+            "c3": "C3: GAT 4 layers x 4 heads x 256 (5 GATConv), fwd+weighted-CE+bwd+AdamW",
+            "c5": "C5: no-grad forward of 7xGraphSAGE-pool-256 + logits projection of every graph to an "
+                  "int16 240^3 partition (fp32 x4 rows)",
+        }
         result = {
-            "metric": "supervoxel-graphs/sec training, 7xSAGE-pool-256, 15k-node graphs",
-            "value": round(value, 3), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "metric": cfg["metric"], "value": round(value, 3),
+            "unit": "volumes/s" if args.config == "c5" else "graphs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "C2: 7xGraphSAGE-pool-256 (8 SAGEConv), fwd+weighted-CE+bwd+AdamW, "
-                                   f"{args.graphs_per_gpu} x 15k-node/{e_b // args.graphs_per_gpu}-edge "
-                                   f"{args.graph_kind} graphs per GPU, 4-chan feat, fp32",
+            "config": {"workload": f"{workloads[args.config]}, {args.graphs_per_gpu} x 15k-node/"
+                                   f"{e_b // args.graphs_per_gpu}-edge {args.graph_kind} graphs per GPU, "
+                                   "4-chan feat, fp32",
                        "global_batch": global_batch, "nodes_per_batch": n_b, "edges_per_batch": e_b,
-                       "parallelism": f"dp{world}", "final_loss": round(float(loss), 6),
+                       "parallelism": f"dp{world}", "last_value": round(float(last), 6),
                        "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3)},
-            "roofline": {"bound": "hbm", "kernel": "spmm_max_fwd_kernel<4,64,1> (F=256, uint8 argmax)",
+            "roofline": {"bound": "hbm", "kernel": cfg["kernel"],
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": round(ms * 1e3, 2) if ms else None,
                          "launches_timed": len(timer.pairs)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.graphs_per_gpu, args.graph_kind, args.cpu_steps)
+        if world == 1 and not args.no_cpu_baseline and args.config != "c5":
+            cpu_steps = 1 if args.config == "c3" else args.cpu_steps   # a GAT step takes ~1 min on the CPU
+            result["cpu_baseline"] = cpu_baseline(cfg, args.graphs_per_gpu, args.graph_kind, cpu_steps)
         print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.barrier()

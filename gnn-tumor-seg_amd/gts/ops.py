@@ -10,9 +10,14 @@ from ._lib import check, current_stream, ptr, require_device
 
 _ARG_DTYPE = {0: torch.uint8, 1: torch.uint8, 4: torch.int32}
 
-# bench.py installs a callable here to bracket each launch of the dominant kernel
-# (spmm_max_fwd at F=256 with argmax) with HIP events; None in normal use.
-DOMINANT_KERNEL_TIMER = None
+# bench.py installs callables here (kernel name -> wrapper) to bracket each launch of a kernel
+# with HIP events; empty in normal use.  Names: "spmm_max_fwd_f256", "gat_fwd", "project_rows".
+KERNEL_TIMERS = {}
+
+
+def _timed(name, launch):
+    timer = KERNEL_TIMERS.get(name)
+    return timer(launch) if timer is not None else launch()
 
 
 def _f32(*tensors):
@@ -40,8 +45,7 @@ def spmm_max_fwd(g, x, want_arg=True):
         return lib.gts_spmm_max_fwd_f32(ptr(d.indptr), ptr(d.indices), ptr(x), ptr(out), ptr(arg),
                                         ab, n, f, current_stream())
 
-    timer = DOMINANT_KERNEL_TIMER
-    code = timer(launch) if (timer is not None and f == 256 and want_arg) else launch()
+    code = _timed("spmm_max_fwd_f256", launch) if (f == 256 and want_arg) else launch()
     check(code, "gts_spmm_max_fwd_f32")
     return out, arg
 
@@ -143,9 +147,10 @@ class _GATAggregate(torch.autograd.Function):
         n, h, dim = ft.shape
         out = torch.empty_like(ft)
         attn = torch.empty((g.number_of_edges(), h), dtype=torch.float32, device=ft.device)
-        check(_lib.load().gts_gat_fwd_f32(ptr(d.indptr), ptr(d.indices), ptr(ft), ptr(el), ptr(er),
-                                          float(negative_slope), ptr(out), ptr(attn), n, h, dim,
-                                          current_stream()), "gts_gat_fwd_f32")
+        lib = _lib.load()
+        check(_timed("gat_fwd", lambda: lib.gts_gat_fwd_f32(
+            ptr(d.indptr), ptr(d.indices), ptr(ft), ptr(el), ptr(er), float(negative_slope), ptr(out),
+            ptr(attn), n, h, dim, current_stream())), "gts_gat_fwd_f32")
         ctx.g, ctx.slope = g, float(negative_slope)
         ctx.save_for_backward(ft, el, er, attn)
         return out
@@ -190,9 +195,10 @@ def project_rows(svs, table, bg_row):
     out = torch.empty(tuple(svs.shape) + tuple(table.shape[1:]), dtype=table.dtype, device=svs.device)
     if svs.numel() == 0:
         return out
-    check(_lib.load().gts_project_rows_i16(ptr(svs), ptr(table), ptr(bg_row), ptr(out), svs.numel(),
-                                           table.shape[0], row_bytes, current_stream()),
-          "gts_project_rows_i16")
+    lib = _lib.load()
+    check(_timed("project_rows", lambda: lib.gts_project_rows_i16(
+        ptr(svs), ptr(table), ptr(bg_row), ptr(out), svs.numel(), table.shape[0], row_bytes,
+        current_stream())), "gts_project_rows_i16")
     return out
 
 

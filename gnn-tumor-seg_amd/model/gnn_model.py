@@ -61,8 +61,10 @@ class GNN:
         self.class_weights = class_weights
         self.net = init_graph_net(model_type, hyperparameters)
         self.net.to(self.device)
+        # same AdamW as the reference (:28); fused=True only selects torch's single-kernel
+        # implementation of the identical update
         self.optimizer = torch.optim.AdamW(self.net.parameters(), lr=hyperparameters.lr,
-                                           weight_decay=hyperparameters.w_decay)
+                                           weight_decay=hyperparameters.w_decay, fused=True)
         self.lr_decay = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, hyperparameters.lr_decay,
                                                                last_epoch=-1)
         # same function as torch.nn.CrossEntropyLoss(weight=class_weights) (reference :30), as one

@@ -1,0 +1,34 @@
+"""ImageGraphDataset + collate on a synthetic on-disk dataset (host side, CPU)."""
+import numpy as np
+import torch
+
+from data_processing.data_loader import ImageGraphDataset, minibatch_graphs
+from oracle import graph_ref
+from tests.dataset_util import write_dataset
+
+
+def test_dataset_items_and_collate(tmp_path):
+    root = str(tmp_path) + "/"
+    truth = write_dataset(root, 3)
+    ds = ImageGraphDataset(root, "BraTS_", read_image=False, read_graph=True, read_label=True)
+    assert len(ds) == 3 and sorted(ds.all_ids) == sorted(truth)
+    mri_id, g, feats, labels = ds[0]
+    svs, node_labels = truth[mri_id]
+    assert feats.dtype == np.float64 and feats.shape == (g.n, 20)
+    assert np.array_equal(labels, node_labels)
+    assert g.ndata["norm"].shape == (g.n, 1)
+    assert np.array_equal(g.ndata["norm"].numpy(), graph_ref.norm_ref(graph_ref.RefGraph(g.src, g.dst, g.n)))
+    assert g.min_in_degree >= 1                               # self loops
+    assert np.array_equal(ds.get_supervoxel_partitioning(mri_id), svs)
+    assert ds.get_voxel_labels(mri_id).dtype == np.int16
+    assert len(ds.get_crop(mri_id)) == 3
+    again = ds[0]
+    assert again[1] is g                                      # parsed once, cached
+    ids, bg, bf, bl = minibatch_graphs([ds[i] for i in range(3)])
+    assert bg.n == sum(ds[i][1].n for i in range(3)) and bg.batch_size == 3
+    assert bf.dtype == torch.float32 and bl.dtype == torch.int64 and bf.shape == (bg.n, 20)
+    unlabeled = ImageGraphDataset(root, "BraTS_", read_image=False, read_graph=True, read_label=False)
+    assert len(unlabeled[0]) == 3
+    both = ImageGraphDataset(root, "BraTS_", read_image=True, read_graph=True, read_label=True)
+    item = both[0]
+    assert len(item) == 6 and item[4].shape == (24, 20, 16, 4) and item[4].dtype == np.float32
