@@ -183,12 +183,12 @@ def gat_aggregate(g, ft, el, er, negative_slope):
 def project_rows(svs, table, bg_row):
     """K12.  svs int16 [...], table [N, ...] with 4/8/16-byte rows, bg_row one such row.
     Returns table_plus_bg[svs] with shape svs.shape + table.shape[1:]."""
-    require_device(svs, table, bg_row)
     if svs.dtype != torch.int16:
         raise _lib.GtsError("supervoxel partitioning must be int16 (mri2graph/graphgen.py:77)")
-    svs = svs.contiguous()
+    svs = svs.contiguous()          # NIfTI volumes arrive in Fortran order: C-order copy, same shape
     table = table.contiguous()
     bg_row = bg_row.to(table.dtype).contiguous()
+    require_device(svs, table, bg_row)
     row_bytes = table.element_size() * (table[0].numel() if table.shape[0] else bg_row.numel())
     if bg_row.numel() * bg_row.element_size() != row_bytes:
         raise _lib.GtsError("background row does not match table rows")
@@ -204,11 +204,11 @@ def project_rows(svs, table, bg_row):
 
 def project_argmax(svs, logits, relabel=None):
     """K12 fused: argmax over classes of the voxel's node, 0 for background; int16 out."""
-    require_device(svs, logits, relabel)
     _f32(logits)
     if svs.dtype != torch.int16:
         raise _lib.GtsError("supervoxel partitioning must be int16")
     svs, logits = svs.contiguous(), logits.contiguous()
+    require_device(svs, logits, relabel)
     if relabel is not None and (relabel.dtype != torch.int16 or relabel.numel() < logits.shape[1]):
         raise _lib.GtsError("relabel must be int16 with one entry per class")
     out = torch.empty(svs.shape, dtype=torch.int16, device=svs.device)

@@ -1,0 +1,24 @@
+#!/bin/bash
+# One GPU-box session: parity tests, headline bench, extra configs, rocprof stats, PMC passes.
+# Usage (through gpurun): bash tools/gpu_validate.sh <tag>
+set -o pipefail
+TAG=${1:-rXX}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+timeout -k 10 600 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1
+echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+tail -4 $OUT/pytest_gpu.log
+if grep -q "Memory access fault" $OUT/pytest_gpu.log; then echo "GPU FAULT"; exit 1; fi
+timeout -k 10 400 python bench.py --steps 30 --warmup 5 > $OUT/bench_c2.json 2> $OUT/bench_c2.err
+tail -1 $OUT/bench_c2.json | cut -c1-330
+timeout -k 10 300 python bench.py --config c5 --steps 20 --warmup 3 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
+tail -1 $OUT/bench_c5.json | cut -c1-330
+timeout -k 10 300 python bench.py --config c3 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c3.json 2> $OUT/bench_c3.err
+tail -1 $OUT/bench_c3.json | cut -c1-330
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_prof.log 2> $OUT/bench_prof.err
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+python tools/parse_pmc.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json | tail -12
+rm -f $OUT/prof/*/*kernel_trace.csv   # large; the stats file is what we keep
+echo done
