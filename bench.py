@@ -24,6 +24,7 @@ Other BASELINE.json configurations (parity-test cases, not the headline) can be 
   --config c5   batched no-grad forward + node->voxel logits projection to 240^3 (volumes/s)
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -190,7 +191,8 @@ def main():
 
     _lib.load()
     torch.manual_seed(0)
-    model = GNN(cfg["model"], hyperparams(cfg), None)
+    with contextlib.redirect_stdout(sys.stderr):   # stdout carries the JSON line only
+        model = GNN(cfg["model"], hyperparams(cfg), None)
     if world > 1:
         for p in model.net.parameters():
             torch.distributed.broadcast(p.data, src=0)

@@ -5,9 +5,12 @@ name, constructor flags, item layout `(mri_id, graph, features[, labels])` and c
 output `(ids, batched_graph, FloatTensor, LongTensor)`; the graph objects are `gts.Graph`
 (int32 CSR, built once per sample) instead of DGLGraphs.
 
-One addition: parsed samples are cached in memory (`cache_graphs=True`) — the reference
-re-parses JSON -> networkx -> graph for every sample of every epoch, which would starve the
-GPU path long before its kernels matter.
+Two additions (the reference re-parses JSON -> networkx -> graph for every sample of every
+epoch, which would starve the GPU path long before its kernels matter):
+  * parsed samples are cached in memory (`cache_graphs=True`);
+  * `cache_dir=...` keeps a binary image of every parsed sample (`{id}.gts.npz`: COO edge
+    list in DGL edge order, features, labels) so later runs skip JSON/networkx entirely.
+    The image is rebuilt whenever the JSON file is newer.
 """
 import glob
 import os
@@ -25,7 +28,7 @@ class ImageGraphDataset(torch.utils.data.Dataset):
     `{id}_label.nii.gz` and `{id}_crop.npy`."""
 
     def __init__(self, dataset_root_dir, mri_start_string, read_image=True, read_graph=True,
-                 read_label=True, cache_graphs=True):
+                 read_label=True, cache_graphs=True, cache_dir=None):
         self.dataset_root_dir = dataset_root_dir
         self.all_ids = self.get_all_mris_in_dataset(dataset_root_dir, mri_start_string)
         self.read_image = read_image
@@ -33,6 +36,9 @@ class ImageGraphDataset(torch.utils.data.Dataset):
         self.read_label = read_label
         assert self.read_graph or self.read_image
         self._graph_cache = {} if cache_graphs else None
+        self.cache_dir = cache_dir
+        if cache_dir is not None:
+            os.makedirs(cache_dir, exist_ok=True)
 
     def get_all_mris_in_dataset(self, dataset_root_dir, mri_start_string):
         folders = glob.glob(f"{dataset_root_dir}**/{mri_start_string}*/", recursive=True)
@@ -55,18 +61,52 @@ class ImageGraphDataset(torch.utils.data.Dataset):
         in_degree^-0.5 with inf -> 0, shape [N,1] (reference data_loader.py:67-83)."""
         if self._graph_cache is not None and mri_id in self._graph_cache:
             return list(self._graph_cache[mri_id])
-        nx_graph = graph_io.load_networkx_graph(self._path(mri_id, "_nxgraph.json"))
-        features = np.array([nx_graph.nodes[n]["features"] for n in nx_graph.nodes])
-        G = gts.from_networkx(nx_graph)
+        json_path = self._path(mri_id, "_nxgraph.json")
+        image = self._load_image(mri_id, json_path)
+        if image is not None:
+            G, features, labels = image
+        else:
+            nx_graph = graph_io.load_networkx_graph(json_path)
+            features = np.array([nx_graph.nodes[n]["features"] for n in nx_graph.nodes])
+            labels = np.array([nx_graph.nodes[n]["label"] for n in nx_graph.nodes]) \
+                if all("label" in nx_graph.nodes[n] for n in nx_graph.nodes) else None
+            G = gts.from_networkx(nx_graph)
+            self._save_image(mri_id, G, features, labels)
         norm = torch.pow(G.in_degrees().float(), -0.5)
         norm[torch.isinf(norm)] = 0
         G.ndata["norm"] = norm.unsqueeze(1)
         item = [G, features]
         if self.read_label:
-            item.append(np.array([nx_graph.nodes[n]["label"] for n in nx_graph.nodes]))
+            if labels is None:
+                raise KeyError(f"{mri_id}: graph nodes carry no 'label' but read_label=True")
+            item.append(labels)
         if self._graph_cache is not None:
             self._graph_cache[mri_id] = tuple(item)
         return item
+
+    def _image_path(self, mri_id):
+        return os.path.join(self.cache_dir, f"{mri_id}.gts.npz")
+
+    def _load_image(self, mri_id, json_path):
+        if self.cache_dir is None:
+            return None
+        path = self._image_path(mri_id)
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(json_path):
+            return None
+        with np.load(path, allow_pickle=False) as z:
+            G = gts.Graph(z["src"], z["dst"], int(z["num_nodes"]))
+            labels = z["labels"] if "labels" in z.files else None
+            return G, z["features"], labels
+
+    def _save_image(self, mri_id, G, features, labels):
+        if self.cache_dir is None:
+            return
+        arrays = dict(src=G.src, dst=G.dst, num_nodes=np.int64(G.n), features=features)
+        if labels is not None:
+            arrays["labels"] = labels
+        tmp = self._image_path(mri_id) + ".tmp.npz"
+        np.savez(tmp, **arrays)
+        os.replace(tmp, self._image_path(mri_id))
 
     def get_voxel_labels(self, mri_id):
         return nifti_io.read_nifti(self._path(mri_id, "_label.nii.gz"), np.int16)

@@ -32,3 +32,22 @@ def test_dataset_items_and_collate(tmp_path):
     both = ImageGraphDataset(root, "BraTS_", read_image=True, read_graph=True, read_label=True)
     item = both[0]
     assert len(item) == 6 and item[4].shape == (24, 20, 16, 4) and item[4].dtype == np.float32
+
+
+def test_binary_graph_image_cache(tmp_path, monkeypatch):
+    from data_processing import graph_io
+
+    root = str(tmp_path / "data") + "/"
+    write_dataset(root, 2)
+    cache = str(tmp_path / "cache")
+    first = ImageGraphDataset(root, "BraTS_", read_image=False, cache_graphs=False, cache_dir=cache)
+    a = first[0]
+    calls = []
+    monkeypatch.setattr(graph_io, "load_networkx_graph", lambda fp: calls.append(fp) or (_ for _ in ()).throw(AssertionError))
+    second = ImageGraphDataset(root, "BraTS_", read_image=False, cache_graphs=False, cache_dir=cache)
+    b = second[0]                                             # served from the image: no JSON parse
+    assert not calls and a[0] == b[0]
+    for name in ("indptr", "indices", "t_indptr", "t_indices", "t_slot", "t_pos", "src", "dst"):
+        assert np.array_equal(getattr(a[1], name), getattr(b[1], name)), name
+    assert np.array_equal(a[2], b[2]) and a[2].dtype == b[2].dtype and np.array_equal(a[3], b[3])
+    assert torch.equal(a[1].ndata["norm"], b[1].ndata["norm"])
