@@ -19,11 +19,12 @@ _workspaces = {}
 
 def _workspace(device, nbytes):
     """Caller-owned scratch for the split-reduction weight gradient (grown on demand, reused:
-    kernels on one stream run in order, so one buffer per device is enough)."""
-    buf = _workspaces.get(device)
+    kernels on one stream run in order, so one buffer per (device, stream) is enough)."""
+    key = (device, current_stream())
+    buf = _workspaces.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-        _workspaces[device] = buf
+        _workspaces[key] = buf
     return buf
 
 

@@ -10,6 +10,8 @@ The pool layer is ONE autograd node (`_SagePoolLayer`): forward and backward are
 out by hand so that the ReLU of fc_pool is folded into the max-pool backward kernel, the
 argmax is kept as one byte per element, and nothing but (h, p, m, arg, out) is retained.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -50,6 +52,24 @@ class _SagePoolLayer(torch.autograd.Function):
         g_ws, g_wn, g_wp, g_bias, g_bp = _pool_layer_weight_grads(g, gp, h, m, w_pool, w_self)
         gh = dense.linear_bwd_input(g, w_self, gp, w_pool) if need[1] else None   # one K=2N pass
         return None, gh, g_wp, g_bp, g_ws, g_wn, g_bias, None, None
+
+
+# Run the weight gradients of the fused stack on a second stream (see _SagePoolStack.backward).
+# GTS_OVERLAP_WGRAD=0 in the environment keeps everything on one stream.
+OVERLAP_WEIGHT_GRADS = os.environ.get("GTS_OVERLAP_WGRAD", "1") != "0"
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device)
+    if s is None:
+        try:
+            priority = torch.cuda.Stream.priority_range()[0]   # least urgent
+        except Exception:                                       # noqa: BLE001 - older runtimes
+            priority = 0
+        s = torch.cuda.Stream(device=device, priority=priority)
+        _side_streams[device] = s
+    return s
 
 
 def _pool_layer_weight_grads(g, gp, h, m, w_pool, w_self):
@@ -97,17 +117,39 @@ class _SagePoolStack(torch.autograd.Function):
         grads = [None] * (5 * n)
         g = gout.contiguous()            # gradient w.r.t. the pre-activation output of layer i
         gx = None
+        # The weight gradients are off the critical path (nothing in the backward chain reads
+        # them), so they go to a second, low-priority HIP stream: their workgroups fill the
+        # CUs that the chain's short GEMMs leave idle in their prologue / epilogue / last round.
+        main = torch.cuda.current_stream()
+        side = _side_stream(g.device) if OVERLAP_WEIGHT_GRADS else None
+        keep_alive = []
         for i in reversed(range(n)):
             h, p, m, arg = acts[4 * i:4 * i + 4]
             w_pool, _b_pool, w_self, w_neigh, _bias = params[5 * i:5 * i + 5]
             gm = dense.linear_bwd_input(g, w_neigh)
             gp = ops.spmm_max_bwd(ctx.g, gm, arg, relu_src=p)
-            g_ws, g_wn, g_wp, g_bias, g_bp = _pool_layer_weight_grads(g, gp, h, m, w_pool, w_self)
+            if side is None:
+                layer_grads = _pool_layer_weight_grads(g, gp, h, m, w_pool, w_self)
+            else:
+                ready = torch.cuda.Event()
+                ready.record(main)                      # g and gp are complete on the main stream
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    layer_grads = _pool_layer_weight_grads(g, gp, h, m, w_pool, w_self)
+                keep_alive.append((g, gp))              # still being read by the side stream
+            g_ws, g_wn, g_wp, g_bias, g_bp = layer_grads
             grads[5 * i:5 * i + 5] = [g_wp, g_bp, g_ws, g_wn, g_bias]
             if i > 0:      # h is layer i-1's ReLU output: its backward is the mask h > 0
                 g = dense.linear_bwd_input(g, w_self, gp, w_pool, relu_mask=h)
             elif ctx.needs_input_grad[1]:
                 gx = dense.linear_bwd_input(g, w_self, gp, w_pool)
+        if side is not None:
+            main.wait_stream(side)
+            for t in grads:
+                t.record_stream(main)                   # allocated on `side`, consumed on `main`
+            for pair in keep_alive:
+                for t in pair:
+                    t.record_stream(side)
         return (None, gx, None, *grads)
 
 
