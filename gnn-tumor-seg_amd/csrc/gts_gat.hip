@@ -34,8 +34,9 @@ template <int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const float* __restrict__ ft, const float* __restrict__ el, const float* __restrict__ er,
-    float slope, float* __restrict__ out, float* __restrict__ attn, int n_rows, int heads,
-    int dim, int seq) {
+    float slope, float* __restrict__ out, float* __restrict__ attn,
+    const float* __restrict__ bias, const float* __restrict__ residual, int act, int n_rows,
+    int heads, int dim, int seq) {
   const int gl = (threadIdx.x & (kWave - 1)) % LPR;
   for (int s = 0; s < seq; ++s) {
     const int r = owned_row<LPR>(s, seq, n_rows);
@@ -79,11 +80,54 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
           }
         }
       });
+      // epilogue of GATConv: + res_fc(h) + bias, then the activation (ELU), all on the way out
       Vec<VEC> o;
 #pragma unroll
       for (int t = 0; t < VEC; ++t) o.v[t] = acc[t];
+      if (residual != nullptr) {
+        const Vec<VEC> rs = Vec<VEC>::load(residual + static_cast<size_t>(r) * dim + c);
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) o.v[t] += rs.v[t];
+      }
+      if (bias != nullptr) {
+        const Vec<VEC> bs = Vec<VEC>::load(bias + static_cast<size_t>(h) * dim + c);
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) o.v[t] += bs.v[t];
+      }
+      if (act == 1) {
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) o.v[t] = o.v[t] > 0.0f ? o.v[t] : expm1f(o.v[t]);
+      }
       if (active) o.store(out + static_cast<size_t>(r) * dim + c);
     });
+  }
+}
+
+// ------------------------------------------------------------------ attention scores
+// el[n,h] = <ft[n,h,:], attn_l[h,:]>, er likewise: one pass over ft for both.
+template <int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void gat_scores_kernel(
+    const float* __restrict__ ft, const float* __restrict__ attn_l,
+    const float* __restrict__ attn_r, float* __restrict__ el, float* __restrict__ er, int n_rows,
+    int heads, int dim, int seq) {
+  const int gl = (threadIdx.x & (kWave - 1)) % LPR;
+  for (int s = 0; s < seq; ++s) {
+    const int r = owned_row<LPR>(s, seq, n_rows);
+    const bool live = r >= 0;          // dead groups still join the wave-wide shuffles with zeros
+    const int h = live ? r % heads : 0;
+    float sl = 0.0f, sr = 0.0f;
+    if (live) {
+      for (int c = gl * VEC; c < dim; c += LPR * VEC) {
+        const Vec<VEC> f = Vec<VEC>::load(ft + static_cast<size_t>(r) * dim + c);
+        const Vec<VEC> al = Vec<VEC>::load(attn_l + static_cast<size_t>(h) * dim + c);
+        const Vec<VEC> ar = Vec<VEC>::load(attn_r + static_cast<size_t>(h) * dim + c);
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) sl += f.v[t] * al.v[t], sr += f.v[t] * ar.v[t];
+      }
+    }
+    sl = group_sum<LPR>(sl);
+    sr = group_sum<LPR>(sr);
+    if (live && gl == 0) el[r] = sl, er[r] = sr;
   }
 }
 
@@ -151,18 +195,18 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_kernel(
     const int32_t* __restrict__ t_indptr, const int32_t* __restrict__ t_indices,
     const int32_t* __restrict__ t_pos, const float* __restrict__ attn,
     const float* __restrict__ ge, const float* __restrict__ gout, float* __restrict__ gft,
-    float* __restrict__ gel, int n_rows, int heads, int dim, int seq) {
+    float* __restrict__ gel, const float* __restrict__ attn_l, const float* __restrict__ attn_r,
+    const float* __restrict__ ger, int n_rows, int heads, int dim, int seq) {
   const int gl = (threadIdx.x & (kWave - 1)) % LPR;
   for (int s = 0; s < seq; ++s) {
     const int r = owned_row<LPR>(s, seq, n_rows);
     if (r < 0) continue;
     const int u = r / heads, h = r - u * heads;
     const int beg = t_indptr[u], end = t_indptr[u + 1];
-    if (gl == 0) {
-      float acc = 0.0f;
-      for (int k = beg; k < end; ++k) acc += ge[static_cast<size_t>(t_pos[k]) * heads + h];
-      gel[r] = acc;
-    }
+    float gel_r = 0.0f;   // every lane of the group adds the same few scalars (no exchange needed)
+    for (int k = beg; k < end; ++k) gel_r += ge[static_cast<size_t>(t_pos[k]) * heads + h];
+    if (gl == 0) gel[r] = gel_r;
+    const float ger_r = ger != nullptr ? ger[r] : 0.0f;
     for_columns<VEC, LPR>(dim, [&](int c, bool active) {
       float acc[VEC];
 #pragma unroll
@@ -189,6 +233,12 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_kernel(
       Vec<VEC> o;
 #pragma unroll
       for (int t = 0; t < VEC; ++t) o.v[t] = acc[t];
+      if (attn_l != nullptr) {   // el = <ft, attn_l>, er = <ft, attn_r>: their gradient w.r.t. ft
+        const Vec<VEC> al = Vec<VEC>::load(attn_l + static_cast<size_t>(h) * dim + c);
+        const Vec<VEC> ar = Vec<VEC>::load(attn_r + static_cast<size_t>(h) * dim + c);
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) o.v[t] += gel_r * al.v[t] + ger_r * ar.v[t];
+      }
       if (active) o.store(gft + static_cast<size_t>(r) * dim + c);
     });
   }
@@ -204,17 +254,20 @@ inline bool bad_gat_shape(int64_t n, int64_t heads, int64_t dim) {
 
 extern "C" int32_t gts_gat_fwd_f32(const int32_t* indptr, const int32_t* indices,
                                    const float* ft, const float* el, const float* er,
-                                   float negative_slope, float* out, float* attn, int64_t n,
-                                   int64_t heads, int64_t dim, void* stream) {
+                                   float negative_slope, const float* bias,
+                                   const float* residual, int32_t activation, float* out,
+                                   float* attn, int64_t n, int64_t heads, int64_t dim,
+                                   void* stream) {
   using namespace gts;
   if (!indptr || !ft || !el || !er || !out || !attn) return GTS_ERR_NULL;
   if (bad_gat_shape(n, heads, dim)) return GTS_ERR_SHAPE;
+  if (activation != 0 && activation != 1) return GTS_ERR_ARGKIND;
   if (n == 0) return GTS_OK;
   const Geometry g = make_geometry(n * heads, dim);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nr = static_cast<int>(n * heads), nh = static_cast<int>(heads), nd = static_cast<int>(dim);
   GTS_DISPATCH_GEOM(g, {
-    gat_fwd_kernel<VEC, LPR><<<g.grid, kBlock, 0, st>>>(indptr, indices, ft, el, er, negative_slope, out, attn, nr, nh, nd, g.seq);
+    gat_fwd_kernel<VEC, LPR><<<g.grid, kBlock, 0, st>>>(indptr, indices, ft, el, er, negative_slope, out, attn, bias, residual, activation, nr, nh, nd, g.seq);
   })
   return launch_status();
 }
@@ -239,18 +292,37 @@ extern "C" int32_t gts_gat_bwd_edge_f32(const int32_t* indptr, const int32_t* in
 
 extern "C" int32_t gts_gat_bwd_src_f32(const int32_t* t_indptr, const int32_t* t_indices,
                                        const int32_t* t_pos, const float* attn,
-                                       const float* ge, const float* gout, float* gft,
-                                       float* gel, int64_t n, int64_t heads, int64_t dim,
-                                       void* stream) {
+                                       const float* ge, const float* gout,
+                                       const float* attn_l, const float* attn_r,
+                                       const float* ger, float* gft, float* gel, int64_t n,
+                                       int64_t heads, int64_t dim, void* stream) {
   using namespace gts;
   if (!t_indptr || !attn || !ge || !gout || !gft || !gel) return GTS_ERR_NULL;
+  if ((attn_l == nullptr) != (attn_r == nullptr) || (attn_l == nullptr) != (ger == nullptr))
+    return GTS_ERR_NULL;
   if (bad_gat_shape(n, heads, dim)) return GTS_ERR_SHAPE;
   if (n == 0) return GTS_OK;
   const Geometry g = make_geometry(n * heads, dim);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nr = static_cast<int>(n * heads), nh = static_cast<int>(heads), nd = static_cast<int>(dim);
   GTS_DISPATCH_GEOM(g, {
-    gat_bwd_src_kernel<VEC, LPR><<<g.grid, kBlock, 0, st>>>(t_indptr, t_indices, t_pos, attn, ge, gout, gft, gel, nr, nh, nd, g.seq);
+    gat_bwd_src_kernel<VEC, LPR><<<g.grid, kBlock, 0, st>>>(t_indptr, t_indices, t_pos, attn, ge, gout, gft, gel, attn_l, attn_r, ger, nr, nh, nd, g.seq);
+  })
+  return launch_status();
+}
+
+extern "C" int32_t gts_gat_scores_f32(const float* ft, const float* attn_l, const float* attn_r,
+                                      float* el, float* er, int64_t n, int64_t heads, int64_t dim,
+                                      void* stream) {
+  using namespace gts;
+  if (!ft || !attn_l || !attn_r || !el || !er) return GTS_ERR_NULL;
+  if (bad_gat_shape(n, heads, dim)) return GTS_ERR_SHAPE;
+  if (n == 0) return GTS_OK;
+  const Geometry g = make_geometry(n * heads, dim);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nr = static_cast<int>(n * heads), nh = static_cast<int>(heads), nd = static_cast<int>(dim);
+  GTS_DISPATCH_GEOM(g, {
+    gat_scores_kernel<VEC, LPR><<<g.grid, kBlock, 0, st>>>(ft, attn_l, attn_r, el, er, nr, nh, nd, g.seq);
   })
   return launch_status();
 }

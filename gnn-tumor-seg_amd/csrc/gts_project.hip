@@ -112,7 +112,7 @@ inline unsigned stream_grid(int64_t n_vox) {
 }  // namespace
 }  // namespace gts
 
-extern "C" int32_t gts_abi_version(void) { return 3; }
+extern "C" int32_t gts_abi_version(void) { return 4; }
 
 extern "C" const char* gts_error_string(int32_t code) {
   switch (code) {

@@ -10,7 +10,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgts_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "gts_hip.h")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -24,9 +24,13 @@ SIGNATURES = {
     "gts_spmm_max_fwd_f32": [_p, _p, _p, _p, _p, _i32, _i64, _i64, _p],
     "gts_spmm_max_bwd_f32": [_p, _p, _p, _p, _p, _i32, _p, _p, _i64, _i64, _p],
     "gts_spmm_sum_f32": [_p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _p],
-    "gts_gat_fwd_f32": [_p, _p, _p, _p, _p, _f32, _p, _p, _i64, _i64, _i64, _p],
+    "gts_gat_fwd_f32": [_p, _p, _p, _p, _p, _f32, _p, _p, _i32, _p, _p, _i64, _i64, _i64, _p],
+    "gts_gat_scores_f32": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
+    "gts_gat_reduce_workspace": [_i64, _i64],
+    "gts_gat_act_bwd_f32": [_p, _p, _i32, _p, _p, _p, _i64, _i64, _i64, _p],
+    "gts_gat_param_grad_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "gts_gat_bwd_edge_f32": [_p, _p, _p, _p, _p, _p, _p, _f32, _p, _p, _i64, _i64, _i64, _p],
-    "gts_gat_bwd_src_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
+    "gts_gat_bwd_src_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     "gts_project_rows_i16": [_p, _p, _p, _p, _i64, _i64, _i32, _p],
     "gts_project_argmax_i16": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
     "gts_linear_fwd_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p],
@@ -38,7 +42,7 @@ SIGNATURES = {
     "gts_weighted_ce_f32": [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p],
 }
 _RESTYPE = {"gts_error_string": ctypes.c_char_p, "gts_linear_bwd_weight_workspace": _i64,
-            "gts_weighted_ce_workspace": _i64}
+            "gts_weighted_ce_workspace": _i64, "gts_gat_reduce_workspace": _i64}
 
 _lib = None
 

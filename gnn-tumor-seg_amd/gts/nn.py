@@ -244,6 +244,61 @@ class SAGEConv(nn.Module):
         return rst
 
 
+# One autograd node per GAT layer (scores, attention, aggregation, residual, bias and ELU fused into
+# the K5-K8 kernels).  GTS_FUSE_GAT=0 keeps the op-by-op path (same kernels for the aggregation,
+# torch for the small elementwise pieces).
+FUSE_GAT_LAYER = os.environ.get("GTS_FUSE_GAT", "1") != "0"
+
+
+class _GATLayer(torch.autograd.Function):
+    """rst = act( softmax-attention aggregate of ft + res_fc(h) + bias ),  ft = h W^T viewed [N,H,D],
+    el/er = <ft, attn_l/r>  — DGL GATConv (reference model/networks.py:46-58) as one node."""
+
+    @staticmethod
+    def forward(ctx, g, h, w_fc, attn_l, attn_r, bias, w_res, identity_res, slope, act_code, heads, dim,
+                need_bwd):
+        h = h.contiguous()
+        n = h.shape[0]
+        ft = dense.linear_fwd(h, w_fc).view(n, heads, dim)
+        al, ar = attn_l.reshape(heads, dim), attn_r.reshape(heads, dim)
+        el, er = ops.gat_scores(ft, al, ar)
+        if w_res is not None:
+            res = dense.linear_fwd(h, w_res)
+        elif identity_res:
+            res = h
+        else:
+            res = None
+        out, attn = ops._gat_fwd(g, ft, el, er, slope, bias, res, act_code)
+        if need_bwd:
+            ctx.g, ctx.slope, ctx.act, ctx.identity_res = g, slope, act_code, identity_res
+            ctx.save_for_backward(h, ft, el, er, attn, out if act_code else None, w_fc, al, ar, w_res)
+            ctx.attn_shape = attn_l.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        h, ft, el, er, attn, out, w_fc, al, ar, w_res = ctx.saved_tensors
+        n, heads, dim = ft.shape
+        need = ctx.needs_input_grad
+        g_pre, g_bias = ops.gat_act_bwd(gout.reshape(n, heads * dim),
+                                        out.view(n, heads * dim) if out is not None else None, ctx.act,
+                                        want_bias_grad=need[5])
+        gft, gel, ger = ops._gat_bwd(ctx.g, ft, el, er, attn, g_pre.view(n, heads, dim), ctx.slope, al, ar)
+        g_al, g_ar = ops.gat_param_grad(ft, gel, ger)
+        gft2 = gft.view(n, heads * dim)
+        g_wres = None
+        if w_res is not None:
+            (g_wfc, _), (g_wres, _) = dense.linear_bwd_weight_multi([(gft2, h, False), (g_pre, h, False)])
+            gh = dense.linear_bwd_input(gft2, w_fc, g_pre, w_res) if need[1] else None
+        else:
+            g_wfc, _ = dense.linear_bwd_weight(gft2, h)
+            gh = dense.linear_bwd_input(gft2, w_fc) if need[1] else None
+            if gh is not None and ctx.identity_res:
+                gh = gh + g_pre
+        return (None, gh, g_wfc, g_al.view(ctx.attn_shape), g_ar.view(ctx.attn_shape), g_bias, g_wres,
+                None, None, None, None, None, None)
+
+
 class GATConv(nn.Module):
     """Graph attention layer (positional order as called at model/networks.py:46-58)."""
 
@@ -294,6 +349,15 @@ class GATConv(nn.Module):
                                       "model/networks.py:77-78 passes no dropout to GAT)")
         n = feat.shape[0]
         h = self.feat_drop(feat)
+        act_code = 0 if self.activation is None else 1 if self.activation in (F.elu, torch.nn.functional.elu) else -1
+        if FUSE_GAT_LAYER and act_code >= 0 and self._out_feats % 4 == 0 and feat.dim() == 2:
+            w_res = self.res_fc.weight if isinstance(self.res_fc, nn.Linear) else None
+            identity_res = isinstance(self.res_fc, nn.Identity)
+            need_bwd = torch.is_grad_enabled() and (
+                h.requires_grad or any(p.requires_grad for p in self.parameters()))
+            return _GATLayer.apply(graph, h, self.fc.weight, self.attn_l, self.attn_r, self.bias, w_res,
+                                   identity_res, self.negative_slope, act_code, self._num_heads,
+                                   self._out_feats, need_bwd)
         ft = dense.linear(h, self.fc.weight).view(n, self._num_heads, self._out_feats)
         el = (ft * self.attn_l).sum(dim=-1)
         er = (ft * self.attn_r).sum(dim=-1)

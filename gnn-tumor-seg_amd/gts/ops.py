@@ -135,6 +135,36 @@ def spmm_reduce(g, x, mode):
 
 
 # ---------------------------------------------------------------- autograd: GAT
+def _gat_fwd(g, ft, el, er, slope, bias=None, residual=None, activation=0):
+    d = g.dev()
+    n, h, dim = ft.shape
+    out = torch.empty_like(ft)
+    attn = torch.empty((g.number_of_edges(), h), dtype=torch.float32, device=ft.device)
+    lib = _lib.load()
+    check(_timed("gat_fwd", lambda: lib.gts_gat_fwd_f32(
+        ptr(d.indptr), ptr(d.indices), ptr(ft), ptr(el), ptr(er), float(slope), ptr(bias), ptr(residual),
+        activation, ptr(out), ptr(attn), n, h, dim, current_stream())), "gts_gat_fwd_f32")
+    return out, attn
+
+
+def _gat_bwd(g, ft, el, er, attn, gout, slope, attn_l=None, attn_r=None):
+    """(gft, gel, ger); with attn_l/attn_r the score-dot-product gradient is folded into gft."""
+    d = g.dev()
+    n, h, dim = ft.shape
+    lib = _lib.load()
+    ge = torch.empty_like(attn)
+    ger = torch.empty_like(er)
+    check(lib.gts_gat_bwd_edge_f32(ptr(d.indptr), ptr(d.indices), ptr(ft), ptr(el), ptr(er), ptr(attn),
+                                   ptr(gout), float(slope), ptr(ge), ptr(ger), n, h, dim,
+                                   current_stream()), "gts_gat_bwd_edge_f32")
+    gft = torch.empty_like(ft)
+    gel = torch.empty_like(el)
+    check(lib.gts_gat_bwd_src_f32(ptr(d.t_indptr), ptr(d.t_indices), ptr(d.t_pos), ptr(attn), ptr(ge),
+                                  ptr(gout), ptr(attn_l), ptr(attn_r), ptr(ger) if attn_l is not None else None,
+                                  ptr(gft), ptr(gel), n, h, dim, current_stream()), "gts_gat_bwd_src_f32")
+    return gft, gel, ger
+
+
 class _GATAggregate(torch.autograd.Function):
     """K5-K8.  (ft [N,H,D], el [N,H], er [N,H]) -> out [N,H,D]."""
 
@@ -143,14 +173,7 @@ class _GATAggregate(torch.autograd.Function):
         ft, el, er = ft.contiguous(), el.contiguous(), er.contiguous()
         _f32(ft, el, er)
         require_device(ft, el, er)
-        d = g.dev()
-        n, h, dim = ft.shape
-        out = torch.empty_like(ft)
-        attn = torch.empty((g.number_of_edges(), h), dtype=torch.float32, device=ft.device)
-        lib = _lib.load()
-        check(_timed("gat_fwd", lambda: lib.gts_gat_fwd_f32(
-            ptr(d.indptr), ptr(d.indices), ptr(ft), ptr(el), ptr(er), float(negative_slope), ptr(out),
-            ptr(attn), n, h, dim, current_stream())), "gts_gat_fwd_f32")
+        out, attn = _gat_fwd(g, ft, el, er, negative_slope)
         ctx.g, ctx.slope = g, float(negative_slope)
         ctx.save_for_backward(ft, el, er, attn)
         return out
@@ -158,25 +181,55 @@ class _GATAggregate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         ft, el, er, attn = ctx.saved_tensors
-        gout = gout.contiguous()
-        g, d = ctx.g, ctx.g.dev()
-        n, h, dim = ft.shape
-        lib = _lib.load()
-        ge = torch.empty_like(attn)
-        ger = torch.empty_like(er)
-        check(lib.gts_gat_bwd_edge_f32(ptr(d.indptr), ptr(d.indices), ptr(ft), ptr(el), ptr(er), ptr(attn),
-                                       ptr(gout), ctx.slope, ptr(ge), ptr(ger), n, h, dim,
-                                       current_stream()), "gts_gat_bwd_edge_f32")
-        gft = torch.empty_like(ft)
-        gel = torch.empty_like(el)
-        check(lib.gts_gat_bwd_src_f32(ptr(d.t_indptr), ptr(d.t_indices), ptr(d.t_pos), ptr(attn), ptr(ge),
-                                      ptr(gout), ptr(gft), ptr(gel), n, h, dim, current_stream()),
-              "gts_gat_bwd_src_f32")
+        gft, gel, ger = _gat_bwd(ctx.g, ft, el, er, attn, gout.contiguous(), ctx.slope)
         return None, gft, gel, ger, None
 
 
 def gat_aggregate(g, ft, el, er, negative_slope):
     return _GATAggregate.apply(g, ft, el, er, negative_slope)
+
+
+def gat_scores(ft, attn_l, attn_r):
+    """(el, er) [N,H]: <ft[n,h,:], attn_l[h,:]>, <ft[n,h,:], attn_r[h,:]> in one pass over ft."""
+    ft, attn_l, attn_r = ft.contiguous(), attn_l.contiguous(), attn_r.contiguous()
+    _f32(ft, attn_l, attn_r)
+    require_device(ft, attn_l, attn_r)
+    n, h, dim = ft.shape
+    el = torch.empty((n, h), dtype=torch.float32, device=ft.device)
+    er = torch.empty_like(el)
+    check(_lib.load().gts_gat_scores_f32(ptr(ft), ptr(attn_l), ptr(attn_r), ptr(el), ptr(er), n, h, dim,
+                                         current_stream()), "gts_gat_scores_f32")
+    return el, er
+
+
+def _reduce_ws(n, cols, device):
+    nbytes = _lib.load().gts_gat_reduce_workspace(n, cols)
+    return torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=device)
+
+
+def gat_act_bwd(gout, out, activation, want_bias_grad):
+    """(g_pre, g_bias): g_pre = gout * act'(out) (ELU via its output), g_bias = g_pre.sum(0)."""
+    gout = gout.contiguous()
+    n, cols = gout.shape[0], gout[0].numel()
+    g_pre = torch.empty_like(gout) if activation else gout
+    g_bias = torch.empty(cols, dtype=torch.float32, device=gout.device) if want_bias_grad else None
+    ws = _reduce_ws(n, cols, gout.device) if want_bias_grad else None
+    check(_lib.load().gts_gat_act_bwd_f32(ptr(gout), ptr(out), activation, ptr(g_pre) if activation else None,
+                                          ptr(g_bias), ptr(ws), ws.numel() * 4 if ws is not None else 0,
+                                          n, cols, current_stream()), "gts_gat_act_bwd_f32")
+    return g_pre, g_bias
+
+
+def gat_param_grad(ft, gel, ger):
+    """(g_attn_l, g_attn_r) [H,D] = sum_n gel[n,h] ft[n,h,:], sum_n ger[n,h] ft[n,h,:]."""
+    n, h, dim = ft.shape
+    gl = torch.empty((h, dim), dtype=torch.float32, device=ft.device)
+    gr = torch.empty_like(gl)
+    ws = _reduce_ws(n, h * dim, ft.device)
+    check(_lib.load().gts_gat_param_grad_f32(ptr(ft), ptr(gel), ptr(ger), ptr(gl), ptr(gr), ptr(ws),
+                                             ws.numel() * 4, n, h, dim, current_stream()),
+          "gts_gat_param_grad_f32")
+    return gl, gr
 
 
 # ---------------------------------------------------------------- node -> voxel projection

@@ -73,29 +73,50 @@ int32_t gts_spmm_sum_f32(const int32_t* indptr, const int32_t* indices, const fl
 
 /* ---- K5-K7: GATConv attention + aggregation (forward) -------------------------------
  * Replaces apply_edges(u_add_v) + leaky_relu + edge_softmax + update_all(u_mul_e, sum)
- * inside GATConv, reached from model/networks.py:46,52,56.
+ * inside GATConv, reached from model/networks.py:46,52,56, plus the layer's tail
+ * (+ res_fc(h) + bias, activation) on the way out.
  *   e_k = leaky_relu(el[src_k,h] + er[v,h]);  a_k = softmax_k(e_k) over row v (max-subtracted)
- *   out[v,h,:] = sum_k a_k * ft[src_k,h,:]
- *   ft [n,H,D], el/er [n,H], out [n,H,D], attn [E,H] in in-CSR slot order (saved for K8). */
+ *   out[v,h,:] = act( sum_k a_k * ft[src_k,h,:] + residual[v,h,:] + bias[h,:] )
+ *   ft [n,H,D], el/er [n,H], out [n,H,D], attn [E,H] in in-CSR slot order (saved for K8);
+ *   bias [H*D] and residual [n,H,D] optional; activation 0 = none, 1 = ELU (alpha 1). */
 int32_t gts_gat_fwd_f32(const int32_t* indptr, const int32_t* indices, const float* ft,
-                        const float* el, const float* er, float negative_slope, float* out,
-                        float* attn, int64_t n, int64_t heads, int64_t dim, void* stream);
+                        const float* el, const float* er, float negative_slope, const float* bias,
+                        const float* residual, int32_t activation, float* out, float* attn,
+                        int64_t n, int64_t heads, int64_t dim, void* stream);
+/* el[n,h] = <ft[n,h,:], attn_l[h,:]>, er[n,h] = <ft[n,h,:], attn_r[h,:]>  (GATConv: (feat * attn).sum(-1)) */
+int32_t gts_gat_scores_f32(const float* ft, const float* attn_l, const float* attn_r, float* el,
+                           float* er, int64_t n, int64_t heads, int64_t dim, void* stream);
 
 /* ---- K8: GATConv backward ------------------------------------------------------------
- * Two passes, both atomics-free:
- *  (1) per destination row (in-CSR):  ga_k = <gout[v,h,:], ft[src_k,h,:]>,
+ * Atomics-free passes:
+ *  (0) gts_gat_act_bwd_f32: g_pre = gout * act'(out) (ELU through its output; activation 0 leaves
+ *      gout as is and g_pre may be NULL) and g_bias[c] = sum_n g_pre[n,c] (optional), cols = H*D.
+ *  (1) per destination row (in-CSR):  ga_k = <g_pre[v,h,:], ft[src_k,h,:]>,
  *      ge_k = a_k*(ga_k - sum_j a_j ga_j) * leaky'(el[src_k]+er[v]);  ger[v,h] = sum_k ge_k;
  *      ge [E,H] written in in-CSR slot order.
- *  (2) per source row (out-CSR): gft[u,h,:] = sum_{e in out(u)} a[slot(e)] * gout[dst_e,h,:],
- *      gel[u,h] = sum_e ge[slot(e)].   t_pos[e] = absolute in-CSR position of out-edge e. */
+ *  (2) per source row (out-CSR): gft[u,h,:] = sum_{e in out(u)} a[pos(e)] * g_pre[dst_e,h,:]
+ *      (+ gel[u,h]*attn_l[h,:] + ger[u,h]*attn_r[h,:] when attn_l/attn_r/ger are given: the
+ *      gradient of the score dot products), gel[u,h] = sum_e ge[pos(e)].
+ *      t_pos[e] = absolute in-CSR position of out-edge e.
+ *  (3) gts_gat_param_grad_f32: g_attn_l[h,:] = sum_n gel[n,h] ft[n,h,:], g_attn_r with ger.
+ * (0) and (3) reduce over the node axis through `workspace`
+ * (>= gts_gat_reduce_workspace(n, H*D) bytes) in a fixed order. */
 int32_t gts_gat_bwd_edge_f32(const int32_t* indptr, const int32_t* indices, const float* ft,
                              const float* el, const float* er, const float* attn,
                              const float* gout, float negative_slope, float* ge, float* ger,
                              int64_t n, int64_t heads, int64_t dim, void* stream);
 int32_t gts_gat_bwd_src_f32(const int32_t* t_indptr, const int32_t* t_indices,
                             const int32_t* t_pos, const float* attn, const float* ge,
-                            const float* gout, float* gft, float* gel, int64_t n,
-                            int64_t heads, int64_t dim, void* stream);
+                            const float* gout, const float* attn_l, const float* attn_r,
+                            const float* ger, float* gft, float* gel, int64_t n, int64_t heads,
+                            int64_t dim, void* stream);
+int64_t gts_gat_reduce_workspace(int64_t n, int64_t cols);
+int32_t gts_gat_act_bwd_f32(const float* gout, const float* out, int32_t activation, float* g_pre,
+                            float* g_bias, float* workspace, int64_t workspace_bytes, int64_t n,
+                            int64_t cols, void* stream);
+int32_t gts_gat_param_grad_f32(const float* ft, const float* gel, const float* ger, float* g_attn_l,
+                               float* g_attn_r, float* workspace, int64_t workspace_bytes, int64_t n,
+                               int64_t heads, int64_t dim, void* stream);
 
 /* ---- K12: node -> voxel projection ----------------------------------------------------
  * Replaces data_processing/graph_io.py:21-24 (project_nodes_to_img) and

@@ -309,3 +309,34 @@ def test_fused_pool_stack_equals_layer_by_layer_path(hp):
     from gts.nn import sage_pool_stack
     plain.train()
     assert sage_pool_stack(g, x, list(plain.layers)) is None
+
+
+@pytest.mark.parametrize("residual,fin,heads,dim,act", [(False, 4, 4, 8, F.elu), (True, 32, 4, 8, F.elu),
+                                                         (True, 12, 2, 16, F.elu), (False, 64, 1, 4, None),
+                                                         (True, 1024, 4, 256, F.elu)])
+def test_fused_gat_layer_equals_op_by_op_path(residual, fin, heads, dim, act, monkeypatch):
+    """Same kernels for attention/aggregation; the fused node only moves scores, bias, residual,
+    ELU and the node-axis reductions into them.  fp32 rounding differs slightly (different
+    summation trees): rtol 1e-5 forward, 1e-4 gradients."""
+    n = 400
+    src, dst = random_coo(n, 2500, seed=fin, min_in_degree=1)
+    g = gts.Graph(src, dst, n).to(DEV)
+    torch.manual_seed(fin)
+    layer = gnn.GATConv(fin, dim, heads, 0, 0, 0.2, residual, act).to(DEV)
+    with torch.no_grad():
+        layer.bias.normal_()
+    x = torch.randn(n, fin, device=DEV) * 0.5
+    gout = torch.randn(n, heads, dim, device=DEV)
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(gnn, "FUSE_GAT_LAYER", fused)
+        layer.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        y = layer(g, xi)
+        y.backward(gout)
+        res.append((y.detach(), xi.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()}))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-4, atol=1e-5 * max(1.0, float(res[1][1].abs().max())))
+    for k in res[0][2]:
+        a, b = res[0][2][k], res[1][2][k]
+        assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * max(1.0, float(b.abs().max()))), k
