@@ -11,7 +11,7 @@ namespace gts {
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int kMaxChunks = 1024;
+constexpr int kMaxChunks = 512;  // two row chunks per CU
 
 inline int64_t rows_per_chunk(int64_t n) { return (n + kMaxChunks - 1) / kMaxChunks; }
 inline int n_chunks(int64_t n) {
@@ -26,6 +26,7 @@ __global__ __launch_bounds__(kBlock) void gat_act_bwd_kernel(
   const int cols4 = cols >> 2;
   for (int q = threadIdx.x; q < cols4; q += kBlock) {
     v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int64_t row = row0; row < row1; ++row) {
       const size_t off = static_cast<size_t>(row) * cols + 4 * q;
       v4f g = *reinterpret_cast<const v4f*>(gout + off);
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(kBlock) void gat_param_grad_kernel(
   for (int q = threadIdx.x; q < cols4; q += kBlock) {
     const int h = (4 * q) / dim;
     v4f al = {0.f, 0.f, 0.f, 0.f}, ar = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int64_t row = row0; row < row1; ++row) {
       const v4f f = *reinterpret_cast<const v4f*>(ft + static_cast<size_t>(row) * cols + 4 * q);
       const float wl = gel[row * heads + h], wr = ger[row * heads + h];
@@ -63,16 +65,28 @@ __global__ __launch_bounds__(kBlock) void gat_param_grad_kernel(
   }
 }
 
-// out[c] = sum over chunks (in chunk order) of partial[chunk][c]
+// out[c] = sum over chunks of partial[chunk][c].  A workgroup covers 16 column groups x 16 chunk
+// lanes: lane j adds chunks j, j+16, ... in order, then the 16 lane totals are added in lane order
+// (a fixed association: bitwise reproducible).
 __global__ __launch_bounds__(kBlock) void sum_chunks_kernel(const float* __restrict__ partial,
                                                            float* __restrict__ out, int cols,
                                                            int chunks) {
-  const int q = blockIdx.x * kBlock + threadIdx.x;
-  if (q >= (cols >> 2)) return;
+  __shared__ v4f part[16][16];
+  const int cg = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int q = blockIdx.x * 16 + cg;
   v4f acc = {0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < chunks; ++b)
-    acc += *reinterpret_cast<const v4f*>(partial + static_cast<size_t>(b) * cols + 4 * q);
-  *reinterpret_cast<v4f*>(out + 4 * q) = acc;
+  if (q < (cols >> 2)) {
+    for (int b = lane; b < chunks; b += 16)
+      acc += *reinterpret_cast<const v4f*>(partial + static_cast<size_t>(b) * cols + 4 * q);
+  }
+  part[lane][cg] = acc;
+  __syncthreads();
+  if (lane == 0 && q < (cols >> 2)) {
+    v4f total = part[0][cg];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) total += part[j][cg];
+    *reinterpret_cast<v4f*>(out + 4 * q) = total;
+  }
 }
 
 inline bool bad(int64_t n, int64_t cols) {
@@ -103,7 +117,7 @@ extern "C" int32_t gts_gat_act_bwd_f32(const float* gout, const float* out, int3
   gat_act_bwd_kernel<<<chunks, kBlock, 0, st>>>(gout, out, activation, g_pre,
                                                 g_bias ? workspace : nullptr, n, nc, rows_per_chunk(n));
   if (g_bias)
-    sum_chunks_kernel<<<(nc / 4 + kBlock - 1) / kBlock, kBlock, 0, st>>>(workspace, g_bias, nc, chunks);
+    sum_chunks_kernel<<<(nc / 4 + 15) / 16, kBlock, 0, st>>>(workspace, g_bias, nc, chunks);
   return launch_status();
 }
 
@@ -122,7 +136,7 @@ extern "C" int32_t gts_gat_param_grad_f32(const float* ft, const float* gel, con
   float* pr = workspace + static_cast<size_t>(chunks) * cols;
   gat_param_grad_kernel<<<chunks, kBlock, 0, st>>>(ft, gel, ger, pl, pr, n, static_cast<int>(heads),
                                                    static_cast<int>(dim), rows_per_chunk(n));
-  const unsigned grid = (nc / 4 + kBlock - 1) / kBlock;
+  const unsigned grid = (nc / 4 + 15) / 16;
   sum_chunks_kernel<<<grid, kBlock, 0, st>>>(pl, g_attn_l, nc, chunks);
   sum_chunks_kernel<<<grid, kBlock, 0, st>>>(pr, g_attn_r, nc, chunks);
   return launch_status();
