@@ -110,6 +110,78 @@ struct OperandTile {
   }
 };
 
+// Epilogue shared by the GEMM kernels.  C/D layout of the 32x32 MFMA: col = lane & 31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  `lds` is the (now dead) operand area.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void write_tile(const GemmArgs& p, float* lds, float* c,
+                                           v16f (&acc)[BM / WM / 32][BN / WN / 32], int m0, int n0) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int i = lane & 31, h = lane >> 5;
+  if ((p.rb & 3) == 0 && (p.ldc & 3) == 0) {
+    // Wide path: each 32x32 accumulator tile goes through a per-wave [32][36] LDS patch (the
+    // operand images are dead after the loop's last barrier) and leaves as 16-byte-per-lane row
+    // segments: 4x fewer store instructions, and bias / ReLU mask arrive as float4 too.
+    float* stage = lds + wave * (32 * kKcLd);
+    const int srow = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = n0 + wn * WTN + tn * 32 + c4;
+      const bool col_ok = col < p.rb;
+      v4f bias = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias != nullptr && col_ok) bias = *reinterpret_cast<const v4f*>(p.bias + col);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * kKcLd + i] = acc[tm][tn][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int lrow = it * 8 + srow;
+          v4f val = *reinterpret_cast<const v4f*>(stage + lrow * kKcLd + c4) + bias;
+          const int row = m0 + wm * WTM + tm * 32 + lrow;
+          if (row < p.ra && col_ok) {
+            const size_t off = static_cast<size_t>(row) * p.ldc + col;
+            if (p.relu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
+            }
+            if (p.mask != nullptr) {
+              const v4f mk = *reinterpret_cast<const v4f*>(p.mask + off);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) val[e] = mk[e] > 0.f ? val[e] : 0.f;
+            }
+            *reinterpret_cast<v4f*>(c + off) = val;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  } else {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = n0 + wn * WTN + tn * 32 + i;
+      const float bias = (p.bias != nullptr && col < p.rb) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * WTM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < p.ra && col < p.rb) {
+            const size_t off = static_cast<size_t>(row) * p.ldc + col;
+            float val = acc[tm][tn][r] + bias;
+            if (p.relu) val = fmaxf(val, 0.f);
+            if (p.mask != nullptr) val = p.mask[off] > 0.f ? val : 0.f;
+            c[off] = val;
+          }
+        }
+      }
+    }
+  }
+}
+
 // waves per SIMD to plan registers for: two co-resident workgroups when the accumulators allow
 constexpr int min_waves_per_simd(int wm, int wn, int tm, int tn) {
   const int per_block = wm * wn / 4;                       // waves per SIMD of one workgroup
@@ -208,76 +280,14 @@ void gemm_kernel(const GemmArgs p) {
     }
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA — col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int i = lane & 31, h = lane >> 5;
   const size_t slab = p.n_problems ? static_cast<size_t>(problem) * p.n_splits + blockIdx.z : 0;
-  float* c = p.c + slab * p.ra * p.ldc;
-  if ((p.rb & 3) == 0 && (p.ldc & 3) == 0) {
-    // Wide path: each 32x32 accumulator tile goes through a per-wave [32][36] LDS patch (the
-    // operand images are dead after the loop's last barrier) and leaves as 16-byte-per-lane row
-    // segments: 4x fewer store instructions, and bias / ReLU mask arrive as float4 too.
-    float* stage = lds + wave * (32 * kKcLd);
-    const int srow = lane >> 3, c4 = (lane & 7) * 4;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int col = n0 + wn * WTN + tn * 32 + c4;
-      const bool col_ok = col < p.rb;
-      v4f bias = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias != nullptr && col_ok) bias = *reinterpret_cast<const v4f*>(p.bias + col);
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * kKcLd + i] = acc[tm][tn][r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int lrow = it * 8 + srow;
-          v4f val = *reinterpret_cast<const v4f*>(stage + lrow * kKcLd + c4) + bias;
-          const int row = m0 + wm * WTM + tm * 32 + lrow;
-          if (row < p.ra && col_ok) {
-            const size_t off = static_cast<size_t>(row) * p.ldc + col;
-            if (p.relu) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
-            }
-            if (p.mask != nullptr) {
-              const v4f mk = *reinterpret_cast<const v4f*>(p.mask + off);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) val[e] = mk[e] > 0.f ? val[e] : 0.f;
-            }
-            *reinterpret_cast<v4f*>(c + off) = val;
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-  } else {
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int col = n0 + wn * WTN + tn * 32 + i;
-      const float bias = (p.bias != nullptr && col < p.rb) ? p.bias[col] : 0.f;
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * WTM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (row < p.ra && col < p.rb) {
-            const size_t off = static_cast<size_t>(row) * p.ldc + col;
-            float val = acc[tm][tn][r] + bias;
-            if (p.relu) val = fmaxf(val, 0.f);
-            if (p.mask != nullptr) val = p.mask[off] > 0.f ? val : 0.f;
-            c[off] = val;
-          }
-        }
-      }
-    }
-  }
+  write_tile<BM, BN, WM, WN>(p, lds, p.c + slab * p.ra * p.ldc, acc, m0, n0);
   if (want_colsum) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const float total = csum[tm] + __shfl_xor(csum[tm], 32, kWave);  // the two kk halves
-      const int row = m0 + wm * WTM + tm * 32 + i;
-      if (h == 0 && row < p.ra) p.colsum[slab * p.ra + row] = total;
+      const int row = m0 + wm * WTM + tm * 32 + (lane & 31);
+      if ((lane >> 5) == 0 && row < p.ra) p.colsum[slab * p.ra + row] = total;
     }
   }
 }
