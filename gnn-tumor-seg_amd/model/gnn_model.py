@@ -97,48 +97,57 @@ class GNN:
         self.optimizer.step()
         return loss.clone()
 
-    def run_epoch(self):
-        self.net.train()
-        losses = []
-        for _ids, batch_graphs, batch_features, batch_labels in self.train_loader:
-            batch_graphs = batch_graphs.to(self.device)
-            batch_features = batch_features.to(self.device)
-            batch_labels = batch_labels.to(self.device)
-            losses.append(self.train_step(batch_graphs, batch_features, batch_labels))
-        self.lr_decay.step()
-        return np.mean(torch.stack(losses).cpu().double().numpy())
+    def _to_device(self, graph, features, labels=None):
+        graph = graph.to(self.device)
+        features = torch.as_tensor(np.asarray(features), dtype=torch.float32).to(self.device) \
+            if not isinstance(features, torch.Tensor) else features.to(self.device, torch.float32)
+        if labels is None:
+            return graph, features
+        labels = torch.as_tensor(np.asarray(labels), dtype=torch.int64).to(self.device) \
+            if not isinstance(labels, torch.Tensor) else labels.to(self.device, torch.int64)
+        return graph, features, labels
 
-    # dataset must be a torch Subset of an ImageGraphDataset (as scripts/train_gnn.py passes)
+    def run_epoch(self):
+        """One pass over the training loader; returns the mean of the per-step losses
+        (reference :34-48).  Losses stay on the device until the epoch ends."""
+        self.net.train()
+        step_losses = [self.train_step(*self._to_device(graph, feats, labels))
+                       for _ids, graph, feats, labels in self.train_loader]
+        self.lr_decay.step()
+        return np.mean(torch.stack(step_losses).cpu().double().numpy())
+
     def evaluate(self, dataset: ImageGraphDataset):
+        """`dataset` is a torch Subset of an ImageGraphDataset with labels (what
+        scripts/train_gnn.py passes).  Per sample: no-grad forward, weighted CE, arg-max; node
+        metrics, then voxel metrics after projecting the predictions onto the supervoxel
+        partitioning (reference :51-87).  Returns (mean of the [n,10] metric rows, sum of the
+        [n,8] label-count rows); metric columns: loss | node Dice WT,CT,ET | voxel Dice WT,CT,ET |
+        voxel HD95 WT,CT,ET."""
         assert dataset.dataset.read_label == True  # noqa: E712
         self.net.eval()
-        # loss | node dice WT,CT,ET | voxel dice WT,CT,ET | voxel HD95 WT,CT,ET
-        metrics = np.zeros((len(dataset), 10))
-        counts = np.zeros((len(dataset), 8))
-        for i, (curr_id, curr_graph, curr_feats, curr_labels) in enumerate(dataset):
-            curr_graph = curr_graph.to(self.device)
-            curr_feats = torch.FloatTensor(curr_feats).to(self.device)
-            curr_labels = torch.LongTensor(curr_labels).to(self.device)
+        metric_rows, count_rows = [], []
+        for mri_id, graph, feats, labels in dataset:
+            graph, feats, labels = self._to_device(graph, feats, labels)
             with torch.no_grad():
-                logits = self.net(curr_graph, curr_feats)
-                loss = self.loss_fcn(logits, curr_labels)
-            _, predicted_classes = torch.max(logits, dim=1)
-            predicted_classes = predicted_classes.detach().cpu().numpy()
-            metrics[i][0] = loss.item()
-            ct, res = self.calculate_all_metrics_for_brain(
-                curr_id, dataset, predicted_classes, curr_labels.detach().cpu().numpy())
-            metrics[i][1:] = res
-            counts[i] = ct
+                logits = self.net(graph, feats)
+                loss = self.loss_fcn(logits, labels)
+                predicted = torch.max(logits, dim=1)[1]
+            counts, scores = self.calculate_all_metrics_for_brain(
+                mri_id, dataset, predicted.cpu().numpy(), labels.cpu().numpy())
+            metric_rows.append(np.concatenate([[loss.item()], scores]))
+            count_rows.append(counts)
+        metrics = np.array(metric_rows).reshape(len(metric_rows), 10)
+        counts = np.array(count_rows).reshape(len(count_rows), 8)
         return np.mean(metrics, axis=0), np.sum(counts, axis=0)
 
     def calculate_all_metrics_for_brain(self, mri_id, dataset, node_preds, node_labels):
+        """(label counts [pred x4, truth x4], [node Dice x3, voxel Dice x3, voxel HD95 x3])."""
+        source = dataset.dataset        # Subset -> underlying ImageGraphDataset
         label_counts = np.concatenate([evaluation.count_node_labels(node_preds),
                                        evaluation.count_node_labels(node_labels)])
         node_dices = evaluation.calculate_node_dices(node_preds, node_labels)
-        sv_partitioning = dataset.dataset.get_supervoxel_partitioning(mri_id)
-        true_voxels = dataset.dataset.get_voxel_labels(mri_id)
-        pred_voxels = project_nodes_to_img(sv_partitioning, node_preds)   # K12 on the GPU
-        voxel_metrics = evaluation.calculate_brats_metrics(pred_voxels, true_voxels)
+        predicted_voxels = project_nodes_to_img(source.get_supervoxel_partitioning(mri_id), node_preds)  # K12
+        voxel_metrics = evaluation.calculate_brats_metrics(predicted_voxels, source.get_voxel_labels(mri_id))
         return label_counts, np.concatenate([node_dices, voxel_metrics])
 
     def save_weights(self, folder, name):

@@ -21,14 +21,18 @@ from utils.training_helpers import (chunk_dataset_into_folds, create_run_progres
 
 
 def document_metrics(fp, description, results):
+    """Console report + one progress-file row (loss and the three voxel Dice scores)."""
     metrics, counts = around(results[0], 4), results[1]
-    print(f"\n#{description} Results#")
-    print("Loss:", metrics[0])
-    print("Predicted Node Counts:", counts[0:4])
-    print("Label Node Counts:", counts[4:8])
-    print(f"WT Node Dice: {metrics[1]}, CT Node Dice: {metrics[2]}, ET Node Dice: {metrics[3]}")
-    print(f"WT Voxel Dice: {metrics[4]}, CT Voxel Dice: {metrics[5]}, ET Voxel Dice: {metrics[6]}")
-    print(f"WT HD95: {metrics[7]}, CT HD95: {metrics[8]}, ET HD95: {metrics[9]}")
+    report = [
+        f"\n#{description} Results#",
+        f"Loss: {metrics[0]}",
+        f"Predicted Node Counts: {counts[0:4]}",
+        f"Label Node Counts: {counts[4:8]}",
+        "WT Node Dice: {}, CT Node Dice: {}, ET Node Dice: {}".format(*metrics[1:4]),
+        "WT Voxel Dice: {}, CT Voxel Dice: {}, ET Voxel Dice: {}".format(*metrics[4:7]),
+        "WT HD95: {}, CT HD95: {}, ET HD95: {}".format(*metrics[7:10]),
+    ]
+    print("\n".join(report))
     if gdist.world()[0] == 0:
         update_progress_file(fp, description, metrics[0], metrics[4:7])
 
@@ -37,56 +41,62 @@ def train_on_full_dataset(args, hyperparams, progress_file_fd, dataset):
     print("Training on full dataset")
     model = GNN(args.model_type, hyperparams, dataset)
     train_on_fold(model, args.output_dir + os.sep, hyperparams.n_epochs, args.run_name, 1)
-    everything = Subset(dataset, range(0, len(dataset)))
-    document_metrics(progress_file_fd, f"{args.run_name}_full", model.evaluate(everything))
+    whole = Subset(dataset, range(len(dataset)))
+    document_metrics(progress_file_fd, f"{args.run_name}_full", model.evaluate(whole))
 
 
 def run_k_fold_val(args, hyperparams, progress_file_fd, dataset, k):
+    """k-fold cross-validation: fold f trains on everything outside [start_f, end_f)."""
     assert k > 1
+    everything = len(dataset)
     for fold, (start, end) in enumerate(chunk_dataset_into_folds(dataset, k), start=1):
-        val_dataset = Subset(dataset, range(start, end))
-        train_dataset = Subset(dataset, list(r_[0:start, end:len(dataset)]))
-        print(f"Fold contains {len(train_dataset)} examples")
-        model = GNN(args.model_type, hyperparams, train_dataset)
+        held_out = Subset(dataset, range(start, end))
+        training = Subset(dataset, list(r_[0:start, end:everything]))
+        print(f"Fold contains {len(training)} examples")
+        model = GNN(args.model_type, hyperparams, training)
         train_on_fold(model, args.output_dir + os.sep, hyperparams.n_epochs, args.run_name, fold)
-        document_metrics(progress_file_fd, f"{args.run_name}_f{fold}_train", model.evaluate(train_dataset))
-        document_metrics(progress_file_fd, f"{args.run_name}_f{fold}_val", model.evaluate(val_dataset))
+        for split, subset in (("train", training), ("val", held_out)):
+            document_metrics(progress_file_fd, f"{args.run_name}_f{fold}_{split}", model.evaluate(subset))
+
+
+_FLAGS = (
+    # short, long, default, type, help
+    ("-d", "--data_dir", Filepaths.PROCESSED_DATA_DIR, str, "preprocessed dataset directory"),
+    ("-o", "--output_dir", Filepaths.LOG_DIR, str, "where checkpoints and the progress file go"),
+    ("-r", "--run_name", None, str, "name under which results are saved"),
+    ("-m", "--model_type", "GSpool", str, "GSpool | GSmean | GSgcn | GAT"),
+    ("-k", "--num_folds", 5, int, "folds for cross-validation; 1 trains on the full dataset"),
+    ("-p", "--data_prefix", "", str, "common prefix of the sample folders, e.g. BraTS2021"),
+)
 
 
 def build_parser():
-    parser = argparse.ArgumentParser()
-    parser.add_argument("-d", "--data_dir", default=Filepaths.PROCESSED_DATA_DIR, type=str,
-                        help="path to the directory where data is stored")
-    parser.add_argument("-o", "--output_dir", default=Filepaths.LOG_DIR, type=str, help="Log directory")
-    parser.add_argument("-r", "--run_name", default=None, type=str, help="A unique name to save results under")
-    parser.add_argument("-m", "--model_type", default="GSpool", type=str,
-                        help="What graph learning layer to use. GSpool, GSmean, GSgcn, GAT")
-    parser.add_argument("-k", "--num_folds", default=5, type=int,
-                        help="How many folds to run k fold validation on. 1== train on full dataset")
-    parser.add_argument("-p", "--data_prefix", default="", type=str,
-                        help="A prefix that all data folders share, i.e. BraTS2021.")
+    """Same flags as the reference CLI (scripts/train_gnn.py:66-76)."""
+    parser = argparse.ArgumentParser(description="Train the supervoxel GNN on MI355X")
+    for short, long_name, default, kind, text in _FLAGS:
+        parser.add_argument(short, long_name, default=default, type=kind, help=text)
     parser.add_argument("-x", "--random_hyperparams", default=False, action="store_true",
-                        help="whether to generate random hyperparameters")
+                        help="draw random hyper-parameters")
     return parser
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    rank, _, _ = gdist.init_from_env()
+    if args.num_folds < 1:
+        raise ValueError("Number of folds must be a positive integer")
+    rank = gdist.init_from_env()[0]
+    args.output_dir = os.path.expanduser(args.output_dir)
     dataset = ImageGraphDataset(os.path.expanduser(args.data_dir), args.data_prefix, read_image=False,
                                 read_graph=True, read_label=True)
-    hyperparams = generate_random_hyperparameters(args.model_type) if args.random_hyperparams \
-        else populate_hardcoded_hyperparameters(args.model_type)
-    args.output_dir = os.path.expanduser(args.output_dir)
+    pick = generate_random_hyperparameters if args.random_hyperparams else populate_hardcoded_hyperparameters
+    hyperparams = pick(args.model_type)
     progress_file_fd = f"{args.output_dir}{os.sep}{args.run_name}.txt"
     if rank == 0:
         create_run_progress_file(progress_file_fd, args.model_type, hyperparams)
     if args.num_folds == 1:
         train_on_full_dataset(args, hyperparams, progress_file_fd, dataset)
-    elif args.num_folds > 1:
-        run_k_fold_val(args, hyperparams, progress_file_fd, dataset, args.num_folds)
     else:
-        raise ValueError("Number of folds must be a positive integer")
+        run_k_fold_val(args, hyperparams, progress_file_fd, dataset, args.num_folds)
 
 
 if __name__ == "__main__":
