@@ -235,24 +235,17 @@ void gemm_kernel(const GemmArgs p) {
   const bool want_colsum = !AKC && p.colsum != nullptr && tile_n == 0 && wn == 0;
 
   v4f ra[TA::kVec], rb[TB::kVec];
-  auto fetch = [&](int t) {
+  auto fetch_a = [&](v4f (&dst)[TA::kVec], int t) {
     const bool second = t >= nt0;
-    const int k0 = (second ? t - nt0 : t) * kBK;
-    TA::load(ra, second ? p.a[1] : a_first, second ? p.lda[1] : p.lda[0], m0, k0, p.ra,
-             second ? p.kseg[1] : p.kseg[0]);
-    TB::load(rb, second ? p.b[1] : b_first, second ? p.ldb[1] : p.ldb[0], n0, k0, p.rb,
-             second ? p.kseg[1] : p.kseg[0]);
+    TA::load(dst, second ? p.a[1] : a_first, second ? p.lda[1] : p.lda[0], m0,
+             (second ? t - nt0 : t) * kBK, p.ra, second ? p.kseg[1] : p.kseg[0]);
   };
-
-  if (t_beg < t_end) {
-    fetch(t_beg);
-    TA::store(ra, lds_a);
-    TB::store(rb, lds_b);
-    __syncthreads();
-  }
-  for (int t = t_beg; t < t_end; ++t) {
-    const bool more = t + 1 < t_end;
-    if (more) fetch(t + 1);  // in flight under the MFMAs below
+  auto fetch_b = [&](int t) {
+    const bool second = t >= nt0;
+    TB::load(rb, second ? p.b[1] : b_first, second ? p.ldb[1] : p.ldb[0], n0,
+             (second ? t - nt0 : t) * kBK, p.rb, second ? p.kseg[1] : p.kseg[0]);
+  };
+  auto compute = [&]() {
 #pragma unroll
     for (int g = 0; g < kBK / 8; ++g) {
       float af[TM][4], bf[TN][4];
@@ -272,6 +265,22 @@ void gemm_kernel(const GemmArgs p) {
           for (int tn = 0; tn < TN; ++tn)
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][j], bf[tn][j], acc[tm][tn], 0, 0, 0);
     }
+  };
+
+  if (t_beg < t_end) {
+    fetch_a(ra, t_beg);
+    fetch_b(t_beg);
+    TA::store(ra, lds_a);
+    TB::store(rb, lds_b);
+    __syncthreads();
+  }
+  for (int t = t_beg; t < t_end; ++t) {
+    const bool more = t + 1 < t_end;
+    if (more) {  // in flight under the MFMAs below
+      fetch_a(ra, t + 1);
+      fetch_b(t + 1);
+    }
+    compute();
     __syncthreads();  // every wave is done reading this tile
     if (more) {
       TA::store(ra, lds_a);
@@ -318,6 +327,134 @@ __global__ __launch_bounds__(kBlock) void reduce_slabs_kernel(const ReduceArgs p
     const v4f total = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
     reinterpret_cast<v4f*>(p.out[q])[i] = total;
   }
+}
+
+// ---- skinny weight gradients -------------------------------------------------------------------
+// When one side of gw[N,K] is tiny (the 4 input channels of the first layer, the 4 classes of the
+// last), a 128-row MFMA tile would be >95 % padding and the problem is a stream anyway:
+//   P[i, j] = sum_m skinny[m, i] * wide[m, j],   i < S <= 9,  j < w (multiple of 4)
+// one 16-byte column group of `wide` per thread, S float4 accumulators, row chunks -> per-chunk
+// partials -> fixed-order chunk sum (same determinism as the slab path).  With ones_row the last
+// P row is sum_m wide[m, :] (the bias gradient when `wide` is g).
+constexpr int kSkinnyMax = 9;
+constexpr int kSkinnyChunks = 512;
+
+template <int S>
+__global__ __launch_bounds__(kBlock) void skinny_wgrad_kernel(const float* __restrict__ skinny, int s_cols,
+                                                             const float* __restrict__ wide,
+                                                             float* __restrict__ partial, int64_t m,
+                                                             int w, int64_t rows_per_chunk) {
+  // 256 threads = (w/4 column groups) x (row lanes): with w = 256 four lanes walk interleaved rows
+  // of the chunk and are combined through LDS in lane order before the partial is written.
+  __shared__ v4f red[kBlock];
+  const int cols4 = w >> 2;
+  const int lanes = cols4 >= kBlock ? 1 : kBlock / cols4;
+  const int rl = cols4 >= kBlock ? 0 : threadIdx.x / cols4;
+  const int64_t row0 = blockIdx.x * rows_per_chunk, row1 = min(m, row0 + rows_per_chunk);
+  for (int q0 = 0; q0 < cols4; q0 += kBlock) {
+    const int q = q0 + (cols4 >= kBlock ? threadIdx.x : threadIdx.x % cols4);
+    const bool live = q < cols4 && rl < lanes;
+    v4f acc[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+#pragma unroll 4
+      for (int64_t row = row0 + rl; row < row1; row += lanes) {
+        const v4f f = *reinterpret_cast<const v4f*>(wide + static_cast<size_t>(row) * w + 4 * q);
+#pragma unroll
+        for (int i = 0; i < S; ++i) acc[i] += (i < s_cols ? skinny[row * s_cols + i] : 1.0f) * f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      v4f total = acc[i];
+      if (lanes > 1) {
+        __syncthreads();
+        red[threadIdx.x] = acc[i];
+        __syncthreads();
+        if (rl == 0 && live) {
+          for (int l = 1; l < lanes; ++l) total += red[l * cols4 + q];
+        }
+      }
+      if (rl == 0 && live)
+        *reinterpret_cast<v4f*>(partial + (static_cast<size_t>(blockIdx.x) * S + i) * w + 4 * q) = total;
+    }
+  }
+}
+
+// out = sum over chunks of partial[chunk][rows*w]; element (i, j) goes to dst0[i*w + j] (direct) or
+// dst0[j*s_cols + i] (transposed) for i < s_cols, and row s_cols (the ones row) to dst1[j].
+// 16 outputs x 16 chunk lanes per workgroup; lane totals are added in lane order (deterministic).
+__global__ __launch_bounds__(kBlock) void skinny_sum_kernel(const float* __restrict__ partial,
+                                                           float* __restrict__ dst0,
+                                                           float* __restrict__ dst1, int rows, int s_cols,
+                                                           int w, int chunks, int transposed) {
+  __shared__ float part[16][16];
+  const int o = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + o;
+  const int total_out = rows * w;
+  float acc = 0.f;
+  if (idx < total_out)
+    for (int c = lane; c < chunks; c += 16) acc += partial[static_cast<size_t>(c) * total_out + idx];
+  part[lane][o] = acc;
+  __syncthreads();
+  if (lane != 0 || idx >= total_out) return;
+  float sum = part[0][o];
+#pragma unroll
+  for (int l = 1; l < 16; ++l) sum += part[l][o];
+  const int i = idx / w, j = idx - i * w;
+  if (i < s_cols)
+    dst0[transposed ? j * s_cols + i : i * w + j] = sum;
+  else if (dst1 != nullptr)
+    dst1[j] = sum;
+}
+
+inline int64_t skinny_workspace_floats(int64_t m, int64_t n, int64_t k) {
+  const int64_t small = n < k ? n : k, big = n < k ? k : n;
+  if (small + 1 > kSkinnyMax || big < 64) return 0;
+  return static_cast<int64_t>(kSkinnyChunks) * (small + 1) * big;
+}
+
+template <int S>
+void launch_skinny(const float* skinny, int s_cols, const float* wide, float* partial, int64_t m, int w,
+                   int chunks, int64_t rpc, hipStream_t st) {
+  skinny_wgrad_kernel<S><<<chunks, kBlock, 0, st>>>(skinny, s_cols, wide, partial, m, w, rpc);
+}
+
+// gw[n,k] (+ gb[n]) of ONE problem through the skinny path; returns false when it does not apply
+bool skinny_wgrad(const float* g, const float* a, float* gw, float* gb, float* workspace, int64_t m,
+                  int64_t n, int64_t k, hipStream_t st) {
+  if (skinny_workspace_floats(m, n, k) == 0) return false;
+  const bool g_is_skinny = n < k;          // gw[n,k] = skinny^T wide directly; else transposed
+  const float* skinny = g_is_skinny ? g : a;
+  const float* wide = g_is_skinny ? a : g;
+  const int s_cols = static_cast<int>(g_is_skinny ? n : k), w = static_cast<int>(g_is_skinny ? k : n);
+  const bool ones_row = !g_is_skinny && gb != nullptr;   // colsum(wide = g) is the bias gradient
+  const int rows = s_cols + (ones_row ? 1 : 0);
+  const int64_t rpc = (m + kSkinnyChunks - 1) / kSkinnyChunks;
+  const int chunks = static_cast<int>((m + rpc - 1) / rpc);
+  switch (rows) {
+    case 1: launch_skinny<1>(skinny, s_cols, wide, workspace, m, w, chunks, rpc, st); break;
+    case 2: launch_skinny<2>(skinny, s_cols, wide, workspace, m, w, chunks, rpc, st); break;
+    case 3: launch_skinny<3>(skinny, s_cols, wide, workspace, m, w, chunks, rpc, st); break;
+    case 4: launch_skinny<4>(skinny, s_cols, wide, workspace, m, w, chunks, rpc, st); break;
+    case 5: launch_skinny<5>(skinny, s_cols, wide, workspace, m, w, chunks, rpc, st); break;
+    case 6: launch_skinny<6>(skinny, s_cols, wide, workspace, m, w, chunks, rpc, st); break;
+    case 7: launch_skinny<7>(skinny, s_cols, wide, workspace, m, w, chunks, rpc, st); break;
+    case 8: launch_skinny<8>(skinny, s_cols, wide, workspace, m, w, chunks, rpc, st); break;
+    default: launch_skinny<9>(skinny, s_cols, wide, workspace, m, w, chunks, rpc, st); break;
+  }
+  skinny_sum_kernel<<<(rows * w + 15) / 16, kBlock, 0, st>>>(
+      workspace, gw, ones_row ? gb : nullptr, rows, s_cols, w, chunks, g_is_skinny ? 0 : 1);
+  if (g_is_skinny && gb != nullptr) {
+    // bias gradient = column sums of the skinny g [m, n]: the same kernel with a 1-column "ones"
+    // operand (s_cols = 0 -> the single P row is sum_m wide) over wide = g needs n % 4 == 0
+    float* part = workspace + static_cast<size_t>(chunks) * rows * w;
+    skinny_wgrad_kernel<1><<<chunks, kBlock, 0, st>>>(nullptr, 0, g, part, m, static_cast<int>(n), rpc);
+    skinny_sum_kernel<<<(static_cast<int>(n) + 15) / 16, kBlock, 0, st>>>(
+        part, nullptr, gb, 1, 0, static_cast<int>(n), chunks, 0);
+  }
+  return true;
 }
 
 inline bool aligned4(int64_t x) { return (x & 3) == 0; }
@@ -449,7 +586,10 @@ extern "C" int64_t gts_linear_bwd_weight_workspace(int64_t m, int64_t n, int64_t
   using namespace gts;
   if (m <= 0 || n <= 0 || k <= 0 || n_problems < 1 || n_problems > kMaxProblems) return 0;
   const int64_t splits = wgrad_splits(m, n, k, n_problems);
-  return n_problems * splits * (n * k + n) * static_cast<int64_t>(sizeof(float));
+  const int64_t slabs = n_problems * splits * (n * k + n);
+  // the skinny path handles one problem at a time: [chunks][small+1][big] (+ [chunks][small] bias)
+  const int64_t skinny = skinny_workspace_floats(m, n, k) + kSkinnyChunks * (n < k ? n : 0);
+  return (slabs > skinny ? slabs : skinny) * static_cast<int64_t>(sizeof(float));
 }
 
 extern "C" int32_t gts_linear_bwd_weight_f32(const float* const* g, const float* const* a,
@@ -469,9 +609,14 @@ extern "C" int32_t gts_linear_bwd_weight_f32(const float* const* g, const float*
     if (!g[q] || !a[q] || !gw[q]) return GTS_ERR_NULL;
     any_bias = any_bias || (gb && gb[q]);
   }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (skinny_workspace_floats(m, n, k) > 0) {   // tiny N or K: streaming kernel, problem by problem
+    for (int q = 0; q < n_problems; ++q)
+      skinny_wgrad(g[q], a[q], gw[q], gb ? gb[q] : nullptr, workspace, m, n, k, st);
+    return launch_status();
+  }
   const int splits = wgrad_splits(m, n, k, n_problems);
   const int tiles = static_cast<int>((m + kBK - 1) / kBK);
-  hipStream_t st = static_cast<hipStream_t>(stream);
   GemmArgs p{};
   // C[n, k] = sum_m g[m, n] * act[m, k]: both operands reduction-strided
   for (int q = 0; q < n_problems; ++q) p.pa[q] = g[q], p.pb[q] = a[q];

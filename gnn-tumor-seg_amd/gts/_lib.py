@@ -74,6 +74,11 @@ def load():
         fn.restype = _RESTYPE.get(name, _i32)
     if lib.gts_abi_version() != ABI_VERSION:
         raise GtsError(f"libgts_hip.so ABI {lib.gts_abi_version()} != expected {ABI_VERSION}: rebuild")
+    # tuning knobs from the environment, e.g. GTS_OPTIONS="1=5,3=1" (option=value pairs, gts_set_option)
+    for pair in filter(None, os.environ.get("GTS_OPTIONS", "").split(",")):
+        opt, val = pair.split("=")
+        if lib.gts_set_option(int(opt), int(val)) != 0:
+            raise GtsError(f"GTS_OPTIONS: unknown option {opt}")
     _lib = lib
     return lib
 
