@@ -259,6 +259,11 @@ def main():
         if os.path.exists(pmc_path):
             with open(pmc_path) as fh:
                 traffic = json.load(fh).get(cfg["kernel"] + "_bytes_per_launch")
+        rocprof_us = None     # kernel-only duration from the committed rocprofv3 summary, for comparison:
+        avg_path = os.path.join(REPO, "profiles", "rocprof_kernel_avg.json")   # event brackets add the
+        if os.path.exists(avg_path):                                             # two kernel boundaries
+            with open(avg_path) as fh:
+                rocprof_us = json.load(fh).get(cfg["kernel"] + "_avg_us")
         workloads = {
             "c2": "C2: 7xGraphSAGE-pool-256 (8 SAGEConv), fwd+weighted-CE+bwd+AdamW",
             "c3": "C3: GAT 4 layers x 4 heads x 256 (5 GATConv), fwd+weighted-CE+bwd+AdamW",
@@ -282,6 +287,7 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": round(ms * 1e3, 2) if ms else None,
+                         "rocprof_avg_launch_us": rocprof_us,
                          "launches_timed": len(timer.pairs)},
         }
         if world == 1 and not args.no_cpu_baseline and args.config != "c5":

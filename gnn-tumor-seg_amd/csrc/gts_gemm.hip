@@ -461,7 +461,7 @@ inline bool aligned4(int64_t x) { return (x & 3) == 0; }
 
 // Tile configurations (runtime-selectable for tuning through gts_set_option).
 // Defaults from tools/tune_gemm.py at M = 60 000, 256-wide (profiles/r01_tune_gemm.log).
-int g_fwd_variant = 3;     // forward kernels (both operands kk-contiguous)
+int g_fwd_variant = 5;     // forward kernels (both operands kk-contiguous)
 int g_igrad_variant = 1;   // input-gradient kernels (B kk-strided)
 int g_wgrad_variant = -1;  // split-reduction kernel; -1 = 2 when problems are batched, else 1
 

@@ -16,7 +16,8 @@ timeout -k 10 300 python bench.py --config c5 --steps 20 --warmup 3 > $OUT/bench
 tail -1 $OUT/bench_c5.json | cut -c1-330
 timeout -k 10 300 python bench.py --config c3 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c3.json 2> $OUT/bench_c3.err
 tail -1 $OUT/bench_c3.json | cut -c1-330
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_prof.log 2> $OUT/bench_prof.err
+# single-stream run for the profile: with the weight-gradient side stream the per-kernel durations overlap
+GTS_OVERLAP_WGRAD=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_prof.log 2> $OUT/bench_prof.err
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 python tools/parse_pmc.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json | tail -12
