@@ -154,6 +154,42 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(
       for (int m = kWave / 2; m >= LPR; m >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, m, kWave));
     }
     float dot_sum = 0.0f;  // sum_j a_j ga_j
+    if constexpr (LPR == kWave) {
+      // one wave per (node, head): the row's source slices are fetched in chunks of <= 8 so that
+      // their loads are in flight together, then the chunk's dot products are reduced with
+      // independent butterflies (the wave is convergent: r is wave-uniform)
+      for_chunks<LPR>(beg, end, [&](auto cnt_c, int k) {
+        constexpr int CNT = decltype(cnt_c)::value;
+        const Chunk<LPR, CNT> src(indices, k, end);
+        float part[CNT];
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) part[j] = 0.0f;
+        for (int c0 = 0; c0 < dim; c0 += LPR * VEC) {
+          const int c = c0 + gl * VEC;
+          const bool active = c < dim;
+          const int cc = active ? c : 0;
+          const Vec<VEC> g = Vec<VEC>::load(gout + static_cast<size_t>(r) * dim + cc);
+          Vec<VEC> f[CNT];
+#pragma unroll
+          for (int j = 0; j < CNT; ++j)
+            f[j] = Vec<VEC>::load(ft + (static_cast<size_t>(src[j]) * heads + h) * dim + cc);
+          if (active) {
+#pragma unroll
+            for (int j = 0; j < CNT; ++j)
+#pragma unroll
+              for (int t = 0; t < VEC; ++t) part[j] += g.v[t] * f[j].v[t];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) part[j] = group_sum<LPR>(part[j]);
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) {
+          const size_t pos = static_cast<size_t>(k + j) * heads + h;
+          dot_sum += attn[pos] * part[j];
+          if (gl == 0) ge[pos] = part[j];
+        }
+      });
+    } else {
     for (int i = 0; i < maxdeg; ++i) {
       const int k = beg + i;
       const bool on = k < end;
@@ -173,6 +209,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(
         dot_sum += attn[pos] * ga;
         if (gl == 0) ge[pos] = ga;
       }
+    }
     }
     if (live && gl == 0) {
       const float er_v = er[r];

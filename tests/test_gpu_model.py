@@ -340,3 +340,47 @@ def test_fused_gat_layer_equals_op_by_op_path(residual, fin, heads, dim, act, mo
     for k in res[0][2]:
         a, b = res[0][2][k], res[1][2][k]
         assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * max(1.0, float(b.abs().max()))), k
+
+
+@pytest.mark.parametrize("aggr", ["pool", "mean", "gcn"])
+def test_sage_layer_with_widths_that_are_not_multiples_of_four(aggr):
+    """5 -> 7 features: the GEMM kernels need 16-byte rows, so the host pads (dense._pad4_*)."""
+    n = 120
+    src, dst = random_coo(n, 700, seed=5)
+    tg, g = ref_and_gts(src, dst, n)
+    torch.manual_seed(5)
+    ref = torch_ref.RefSAGEConv(5, 7, aggr, activation=F.relu)
+    mine = gnn.SAGEConv(5, 7, aggr, activation=F.relu)
+    copy_state(mine, ref)
+    mine.to(DEV)
+    x = torch.randn(n, 5)
+    gout = torch.randn(n, 7)
+    xr = x.clone().requires_grad_(True)
+    ref(tg, xr).backward(gout)
+    xd = x.to(DEV).requires_grad_(True)
+    yd = mine(g.to(DEV), xd)
+    yd.backward(gout.to(DEV))
+    _close(yd, ref(tg, x), 1e-5, 1e-5)
+    _close(xd.grad, xr.grad, 1e-4, 1e-5)
+    for (name, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        _close(p.grad, q.grad, 1e-4, 2e-5 * max(1.0, float(q.grad.abs().max())))
+
+
+def test_gat_layer_with_odd_head_width_uses_the_op_by_op_path():
+    n = 90
+    src, dst = random_coo(n, 500, seed=6, min_in_degree=1)
+    tg, g = ref_and_gts(src, dst, n)
+    torch.manual_seed(6)
+    ref = torch_ref.RefGATConv(10, 6, 3, residual=True, activation=F.elu)     # D = 6: not a multiple of 4
+    mine = gnn.GATConv(10, 6, 3, 0, 0, 0.2, True, F.elu)
+    copy_state(mine, ref)
+    mine.to(DEV)
+    x = torch.randn(n, 10) * 0.5
+    gout = torch.randn(n, 3, 6)
+    xr = x.clone().requires_grad_(True)
+    ref(tg, xr).backward(gout)
+    xd = x.to(DEV).requires_grad_(True)
+    yd = mine(g.to(DEV), xd)
+    yd.backward(gout.to(DEV))
+    _close(yd, ref(tg, x), 1e-4, 1e-5)
+    _close(xd.grad, xr.grad, 1e-3, 1e-5)
