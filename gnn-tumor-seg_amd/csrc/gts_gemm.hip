@@ -55,6 +55,9 @@ struct GemmArgs {
   int tiles_n;          // output tiles along rb per problem
   int n_splits;
   int tiles_per_split;  // reduction tiles handled by one blockIdx.z
+#ifdef GTS_GEMM_STAMPS
+  unsigned long long* stamps;  // diagnostic build only: 4 x s_memrealtime per workgroup
+#endif
 };
 
 template <int ROWS, bool KC, int THREADS>
@@ -267,6 +270,10 @@ void gemm_kernel(const GemmArgs p) {
     }
   };
 
+#ifdef GTS_GEMM_STAMPS
+  const size_t stamp_at = 4 * (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x);
+  if (threadIdx.x == 0 && p.stamps) p.stamps[stamp_at] = __builtin_amdgcn_s_memrealtime();
+#endif
   if (t_beg < t_end) {
     fetch_a(ra, t_beg);
     fetch_b(t_beg);
@@ -274,6 +281,9 @@ void gemm_kernel(const GemmArgs p) {
     TB::store(rb, lds_b);
     __syncthreads();
   }
+#ifdef GTS_GEMM_STAMPS
+  if (threadIdx.x == 0 && p.stamps) p.stamps[stamp_at + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int t = t_beg; t < t_end; ++t) {
     const bool more = t + 1 < t_end;
     if (more) {  // in flight under the MFMAs below
@@ -289,8 +299,15 @@ void gemm_kernel(const GemmArgs p) {
     }
   }
 
+#ifdef GTS_GEMM_STAMPS
+  if (threadIdx.x == 0 && p.stamps) p.stamps[stamp_at + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
   const size_t slab = p.n_problems ? static_cast<size_t>(problem) * p.n_splits + blockIdx.z : 0;
   write_tile<BM, BN, WM, WN>(p, lds, p.c + slab * p.ra * p.ldc, acc, m0, n0);
+#ifdef GTS_GEMM_STAMPS
+  __syncthreads();
+  if (threadIdx.x == 0 && p.stamps) p.stamps[stamp_at + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
   if (want_colsum) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -460,6 +477,9 @@ bool skinny_wgrad(const float* g, const float* a, float* gw, float* gb, float* w
 inline bool aligned4(int64_t x) { return (x & 3) == 0; }
 
 // Tile configurations (runtime-selectable for tuning through gts_set_option).
+#ifdef GTS_GEMM_STAMPS
+unsigned long long* g_stamps = nullptr;  // diagnostic build only (tools/diag/gemm_stamps.py)
+#endif
 // Defaults from tools/tune_gemm.py at M = 60 000, 256-wide (profiles/r01_tune_gemm.log).
 int g_fwd_variant = 5;     // forward kernels (both operands kk-contiguous)
 int g_igrad_variant = 1;   // input-gradient kernels (B kk-strided)
@@ -468,6 +488,9 @@ int g_wgrad_variant = -1;  // split-reduction kernel; -1 = 2 when problems are b
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
 int launch_tiles(const GemmArgs& p, int grid_y_mult, int splits, hipStream_t st) {
   GemmArgs q = p;
+#ifdef GTS_GEMM_STAMPS
+  q.stamps = g_stamps;
+#endif
   q.tiles_n = (p.rb + BN - 1) / BN;
   dim3 grid((p.ra + BM - 1) / BM, q.tiles_n * grid_y_mult, splits);
   gemm_kernel<BM, BN, WM, WN, AKC, BKC><<<grid, 64 * WM * WN, 0, st>>>(q);
@@ -524,6 +547,10 @@ int launch_wgrad(const GemmArgs& p, int splits, hipStream_t st) {
 
 }  // namespace
 }  // namespace gts
+
+#ifdef GTS_GEMM_STAMPS
+extern "C" void gts_diag_set_stamps(unsigned long long* buf) { gts::g_stamps = buf; }
+#endif
 
 extern "C" int32_t gts_set_option(int32_t option, int32_t value) {
   switch (option) {

@@ -1,0 +1,51 @@
+"""Diagnostic: per-workgroup phase timeline of the K11 forward GEMM at the C2 layer shape.
+Builds a -DGTS_GEMM_STAMPS copy of the library (never shipped) and prints when workgroups start,
+how long prologue / main loop / epilogue take and when the last one ends.
+  python tools/diag/gemm_stamps.py      (on the GPU box)"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(REPO, "gnn-tumor-seg_amd"))
+import torch  # noqa: E402
+
+so = "/tmp/libgts_stamps.so"
+src = [os.path.join(REPO, "gnn-tumor-seg_amd/csrc", f) for f in ("gts_gemm.hip", "gts_project.hip")]
+subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off",
+                       "-DGTS_GEMM_STAMPS", f"-I{REPO}/include", f"-I{REPO}/gnn-tumor-seg_amd/csrc", "-o", so, *src])
+lib = ctypes.CDLL(so)
+p, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+lib.gts_linear_fwd_f32.argtypes = [p, p, p, p, p, p, i64, i64, i64, i64, i32, p]
+lib.gts_diag_set_stamps.argtypes = [p]
+lib.gts_set_option.argtypes = [i32, i32]
+M, F = 60000, 256
+x = torch.randn(M, F, device="cuda"); y = torch.randn(M, F, device="cuda")
+w = torch.randn(F, F, device="cuda") * 0.05; w2 = torch.randn(F, F, device="cuda") * 0.05
+b = torch.randn(F, device="cuda"); out = torch.empty(M, F, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+for variant, bm, bn in ((3, 64, 256), (5, 256, 128), (1, 128, 256)):
+    lib.gts_set_option(1, variant)
+    n_blocks = ((M + bm - 1) // bm) * ((F + bn - 1) // bn)
+    stamps = torch.zeros(4 * n_blocks, dtype=torch.int64, device="cuda")
+    for dual in (False, True):
+        for rep in range(3):   # last repetition is reported
+            stamps.zero_()
+            lib.gts_diag_set_stamps(stamps.data_ptr())
+            lib.gts_linear_fwd_f32(x.data_ptr(), w.data_ptr(), y.data_ptr() if dual else None,
+                                   w2.data_ptr() if dual else None, b.data_ptr(), out.data_ptr(), M, F, F,
+                                   F if dual else 0, 1, st)
+            torch.cuda.synchronize()
+        t = stamps.cpu().numpy().reshape(n_blocks, 4).astype(np.float64) * 0.01   # 100 MHz -> us
+        t0 = t[:, 0].min()
+        start, pro, main, epi = t[:, 0] - t0, t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
+        end = t[:, 3] - t0
+        q = lambda a: f"p10 {np.percentile(a, 10):6.1f} med {np.median(a):6.1f} p90 {np.percentile(a, 90):6.1f} max {a.max():6.1f}"  # noqa: E731
+        first_round = start < 2.0
+        print(f"variant {variant} ({bm}x{bn}) {'pair' if dual else 'single'}: {n_blocks} workgroups, kernel span {end.max():6.1f} us")
+        print(f"   start   {q(start)}   ({first_round.sum()} start within 2 us)")
+        print(f"   prologue {q(pro)}\n   mainloop {q(main)}\n   epilogue {q(epi)}")
+        print(f"   end     {q(end)}", flush=True)
