@@ -481,7 +481,7 @@ inline bool aligned4(int64_t x) { return (x & 3) == 0; }
 unsigned long long* g_stamps = nullptr;  // diagnostic build only (tools/diag/gemm_stamps.py)
 #endif
 // Defaults from tools/tune_gemm.py at M = 60 000, 256-wide (profiles/r01_tune_gemm.log).
-int g_fwd_variant = 5;     // forward kernels (both operands kk-contiguous)
+int g_fwd_variant = 3;     // forward kernels (both operands kk-contiguous); 5 is equal in-bench but slows the K1 launch that follows
 int g_igrad_variant = 1;   // input-gradient kernels (B kk-strided)
 int g_wgrad_variant = -1;  // split-reduction kernel; -1 = 2 when problems are batched, else 1
 
