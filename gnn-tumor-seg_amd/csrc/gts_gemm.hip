@@ -479,6 +479,7 @@ inline bool aligned4(int64_t x) { return (x & 3) == 0; }
 // Tile configurations (runtime-selectable for tuning through gts_set_option).
 #ifdef GTS_GEMM_STAMPS
 unsigned long long* g_stamps = nullptr;  // diagnostic build only (tools/diag/gemm_stamps.py)
+int g_diag_flags = 0;
 #endif
 // Defaults from tools/tune_gemm.py at M = 60 000, 256-wide (profiles/r01_tune_gemm.log).
 int g_fwd_variant = 3;     // forward kernels (both operands kk-contiguous); 5 is equal in-bench but slows the K1 launch that follows
@@ -490,6 +491,7 @@ int launch_tiles(const GemmArgs& p, int grid_y_mult, int splits, hipStream_t st)
   GemmArgs q = p;
 #ifdef GTS_GEMM_STAMPS
   q.stamps = g_stamps;
+  if (g_diag_flags & 1) q.lda[0] = q.lda[1] = 0;  // every row tile reads the same (cache-hot) A rows
 #endif
   q.tiles_n = (p.rb + BN - 1) / BN;
   dim3 grid((p.ra + BM - 1) / BM, q.tiles_n * grid_y_mult, splits);
@@ -550,6 +552,7 @@ int launch_wgrad(const GemmArgs& p, int splits, hipStream_t st) {
 
 #ifdef GTS_GEMM_STAMPS
 extern "C" void gts_diag_set_stamps(unsigned long long* buf) { gts::g_stamps = buf; }
+extern "C" void gts_diag_set_flags(int flags) { gts::g_diag_flags = flags; }
 #endif
 
 extern "C" int32_t gts_set_option(int32_t option, int32_t value) {

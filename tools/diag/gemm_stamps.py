@@ -21,6 +21,7 @@ lib = ctypes.CDLL(so)
 p, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
 lib.gts_linear_fwd_f32.argtypes = [p, p, p, p, p, p, i64, i64, i64, i64, i32, p]
 lib.gts_diag_set_stamps.argtypes = [p]
+lib.gts_diag_set_flags.argtypes = [i32]
 lib.gts_set_option.argtypes = [i32, i32]
 M, F = 60000, 256
 x = torch.randn(M, F, device="cuda"); y = torch.randn(M, F, device="cuda")
@@ -49,3 +50,24 @@ for variant, bm, bn in ((3, 64, 256), (5, 256, 128), (1, 128, 256)):
         print(f"   start   {q(start)}   ({first_round.sum()} start within 2 us)")
         print(f"   prologue {q(pro)}\n   mainloop {q(main)}\n   epilogue {q(epi)}")
         print(f"   end     {q(end)}", flush=True)
+
+# A operand cache-hot (row stride 0 in the diagnostic build): is the main loop waiting on A from HBM?
+lib.gts_diag_set_stamps(None)
+for variant in (3, 1):
+    lib.gts_set_option(1, variant)
+    for flags in (0, 1):
+        lib.gts_diag_set_flags(flags)
+        for dual in (False, True):
+            args = (x.data_ptr(), w.data_ptr(), y.data_ptr() if dual else None, w2.data_ptr() if dual else None,
+                    b.data_ptr(), out.data_ptr(), M, F, F, F if dual else 0, 1, st)
+            for _ in range(3):
+                lib.gts_linear_fwd_f32(*args)
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(20):
+                lib.gts_linear_fwd_f32(*args)
+            e.record()
+            torch.cuda.synchronize()
+            print(f"variant {variant} A-hot={flags} {'pair' if dual else 'single'}: {s.elapsed_time(e) * 50:.1f} us", flush=True)
+lib.gts_diag_set_flags(0)
