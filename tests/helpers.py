@@ -1,6 +1,5 @@
 """Shared test helpers (CPU side): small graphs, oracle/product pairing."""
 import numpy as np
-import torch
 
 from oracle import graph_ref, torch_ref
 
