@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void spmm_max_fwd_kernel(
       }
       const size_t off = static_cast<size_t>(v) * n_feat + c;
       if (active) {
-        if (nt) o.store_nt(out + off); else o.store(out + off);
+        if (nt & 1) o.store_nt(out + off); else o.store(out + off);
         if constexpr (ARGB != 0) store_slots<VEC, ARGB>(arg, off, slot);
       }
     });
@@ -162,14 +162,14 @@ __global__ __launch_bounds__(kBlock) void spmm_max_bwd_kernel(
       const size_t off = static_cast<size_t>(u) * n_feat + c;
       Vec<VEC> o;
       if (relu_src != nullptr) {
-        const Vec<VEC> p = nt ? Vec<VEC>::load_nt(relu_src + off) : Vec<VEC>::load(relu_src + off);
+        const Vec<VEC> p = (nt & 2) ? Vec<VEC>::load_nt(relu_src + off) : Vec<VEC>::load(relu_src + off);
 #pragma unroll
         for (int t = 0; t < VEC; ++t) o.v[t] = p.v[t] > 0.0f ? acc[t] : 0.0f;
       } else {
 #pragma unroll
         for (int t = 0; t < VEC; ++t) o.v[t] = acc[t];
       }
-      if (active) { if (nt) o.store_nt(gx + off); else o.store(gx + off); }
+      if (active) { if (nt & 1) o.store_nt(gx + off); else o.store(gx + off); }
     });
   }
 }
@@ -261,7 +261,7 @@ extern "C" int32_t gts_spmm_max_bwd_f32(const int32_t* t_indptr, const int32_t* 
   if (arg_bytes != 1 && arg_bytes != 4) return GTS_ERR_ARGKIND;
   if (n_src == 0) return GTS_OK;
   const Geometry g = make_geometry(n_src, n_feat, /*preferred_seq=*/1);
-  const int nt = g_spmm_nt < 0 ? 0 : g_spmm_nt;
+  const int nt = g_spmm_nt < 0 ? 1 : g_spmm_nt;  // streaming stores of gx; never streaming loads of relu_src
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int ns = static_cast<int>(n_src), nf = static_cast<int>(n_feat);
   GTS_DISPATCH_GEOM(g, {
