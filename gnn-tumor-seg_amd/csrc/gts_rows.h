@@ -96,9 +96,10 @@ struct Chunk {
 // rows each wave walks sequentially: enough tiles to fill 256 CUs several times over,
 // few enough that index prefetch amortises.
 // Tuning knobs (gts_set_option).  Defaults come from tools/tune_spmm.py on 4 x 15k-node lattice
-// graphs at F = 256 (profiles/r01_tune_spmm.log): K1 is fastest with 2 rows per wave, K2 with 1; both
-// with streaming (non-temporal) stores of their write-once outputs; streaming LOADS of K2's
-// read-once relu_src rows cost 40 % (bit 1 of the knob).
+// graphs at F = 256 (profiles/r01_tune_spmm.log): K1 is fastest with 2 rows per wave and streaming
+// (non-temporal) stores of out/argmax; K2 with 1 row per wave.  K2's streaming stores win 2 % in
+// isolation but lose 0.5 % inside the training step (the next GEMM reads gx), streaming LOADS of its
+// relu_src rows cost 40 % (bit 1 of the knob): K2 keeps ordinary loads and stores.
 inline int g_spmm_seq = 0;   // rows per wave; 0 = the kernel's own default
 inline int g_spmm_nt = -1;   // streaming stores/loads of write-once / read-once rows; -1 = default
 
