@@ -484,7 +484,9 @@ int g_diag_flags = 0;
 // Defaults from tools/tune_gemm.py at M = 60 000, 256-wide (profiles/r01_tune_gemm.log).
 int g_fwd_variant = 3;     // forward kernels (both operands kk-contiguous); 5 is equal in-bench but slows the K1 launch that follows
 int g_igrad_variant = 1;   // input-gradient kernels (B kk-strided)
-int g_wgrad_variant = -1;  // split-reduction kernel; -1 = 2 when problems are batched, else 1
+int g_wgrad_variant = -1;  // split-reduction kernel; -1 = 2 (128x256) when problems are batched, else 1
+                           // (in isolation 0/1 are 5 % faster for the batch, inside the step — where it
+                           // overlaps the input-gradient chain on the side stream — 2 wins by 1.3 %)
 
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
 int launch_tiles(const GemmArgs& p, int grid_y_mult, int splits, hipStream_t st) {
@@ -531,7 +533,8 @@ inline int wgrad_splits(int64_t m, int64_t n, int64_t k, int n_problems) {
   wgrad_tile(k, n_problems, &bm, &bn);
   const int64_t tiles = (m + kBK - 1) / kBK;
   const int64_t out_tiles = ((n + bm - 1) / bm) * ((k + bn - 1) / bn) * n_problems;
-  int64_t splits = (512 + out_tiles - 1) / out_tiles;  // ~2 workgroups per CU in flight
+  // 2 workgroups per CU = 512 slots; never one more workgroup than slots (a lone tail round)
+  int64_t splits = out_tiles >= 512 ? 1 : 512 / out_tiles;
   if (splits > tiles) splits = tiles;
   return static_cast<int>(splits < 1 ? 1 : splits);
 }
