@@ -321,28 +321,36 @@ void gemm_kernel(const GemmArgs p) {
 // out_q[i] = sum_s slab[q][s][i] for problems q, summed in split order inside four interleaved
 // split groups whose partials are then added in group order: a fixed association, so results
 // are bitwise reproducible.  One float4 column per thread-quad.
-struct ReduceArgs {
-  const float* slabs;
-  float* out[kMaxProblems];
-  int64_t n4;  // float4 per problem
+struct ReduceArgs {   // up to 4 weight-slab jobs + 4 bias-slab jobs in one launch (blockIdx.y = job)
+  const float* slabs[2 * kMaxProblems];
+  float* out[2 * kMaxProblems];
+  int n4[2 * kMaxProblems];  // float4 per job
   int splits;
 };
 
 __global__ __launch_bounds__(kBlock) void reduce_slabs_kernel(const ReduceArgs p) {
   __shared__ v4f part[4][64];
   const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * 64 + col;
   const int q = blockIdx.y;
+  // ternary selection: no runtime index into the by-value argument struct (scratch memory)
+  const float* slabs = q == 0 ? p.slabs[0] : q == 1 ? p.slabs[1] : q == 2 ? p.slabs[2] : q == 3 ? p.slabs[3]
+                     : q == 4 ? p.slabs[4] : q == 5 ? p.slabs[5] : q == 6 ? p.slabs[6] : p.slabs[7];
+  float* out = q == 0 ? p.out[0] : q == 1 ? p.out[1] : q == 2 ? p.out[2] : q == 3 ? p.out[3]
+             : q == 4 ? p.out[4] : q == 5 ? p.out[5] : q == 6 ? p.out[6] : p.out[7];
+  const int n4 = q == 0 ? p.n4[0] : q == 1 ? p.n4[1] : q == 2 ? p.n4[2] : q == 3 ? p.n4[3]
+               : q == 4 ? p.n4[4] : q == 5 ? p.n4[5] : q == 6 ? p.n4[6] : p.n4[7];
+  const int i = blockIdx.x * 64 + col;
+  if (blockIdx.x * 64 >= n4) return;   // whole workgroup past this job's end
   v4f acc = {0.f, 0.f, 0.f, 0.f};
-  if (i < p.n4) {
-    const v4f* src = reinterpret_cast<const v4f*>(p.slabs) + static_cast<size_t>(q) * p.splits * p.n4 + i;
-    for (int s = grp; s < p.splits; s += 4) acc += src[static_cast<size_t>(s) * p.n4];
+  if (i < n4) {
+    const v4f* src = reinterpret_cast<const v4f*>(slabs) + i;
+    for (int s = grp; s < p.splits; s += 4) acc += src[static_cast<size_t>(s) * n4];
   }
   part[grp][col] = acc;
   __syncthreads();
-  if (grp == 0 && i < p.n4) {
+  if (grp == 0 && i < n4) {
     const v4f total = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
-    reinterpret_cast<v4f*>(p.out[q])[i] = total;
+    reinterpret_cast<v4f*>(out)[i] = total;
   }
 }
 
@@ -663,18 +671,20 @@ extern "C" int32_t gts_linear_bwd_weight_f32(const float* const* g, const float*
   p.tiles_per_split = (tiles + splits - 1) / splits;
   int rc = launch_wgrad(p, splits, st);
   if (rc != GTS_OK) return rc;
+  // one reduction launch: weight slabs of every problem, then the bias slabs that were asked for
   ReduceArgs r{};
-  r.slabs = workspace, r.n4 = n * k / 4, r.splits = splits;
-  for (int q = 0; q < n_problems; ++q) r.out[q] = gw[q];
-  reduce_slabs_kernel<<<dim3(static_cast<unsigned>((r.n4 + 63) / 64), n_problems), kBlock, 0, st>>>(r);
-  if (any_bias) {
-    // bias slabs are contiguous per problem like the weight slabs; problems without a gb
-    // pointer still need a destination, so they reduce into the (dead) head of their own slab
-    ReduceArgs rb{};
-    rb.slabs = p.colsum, rb.n4 = n / 4, rb.splits = splits;
-    for (int q = 0; q < n_problems; ++q)
-      rb.out[q] = gb[q] ? gb[q] : workspace + (static_cast<size_t>(q) * splits) * n * k;
-    reduce_slabs_kernel<<<dim3(static_cast<unsigned>((rb.n4 + 63) / 64), n_problems), kBlock, 0, st>>>(rb);
+  r.splits = splits;
+  int jobs = 0;
+  for (int q = 0; q < n_problems; ++q, ++jobs) {
+    r.slabs[jobs] = workspace + static_cast<size_t>(q) * splits * n * k;
+    r.out[jobs] = gw[q], r.n4[jobs] = static_cast<int>(n * k / 4);
   }
+  for (int q = 0; q < n_problems && any_bias; ++q) {
+    if (!gb[q]) continue;
+    r.slabs[jobs] = p.colsum + static_cast<size_t>(q) * splits * n;
+    r.out[jobs] = gb[q], r.n4[jobs] = static_cast<int>(n / 4);
+    ++jobs;
+  }
+  reduce_slabs_kernel<<<dim3(static_cast<unsigned>((n * k / 4 + 63) / 64), jobs), kBlock, 0, st>>>(r);
   return launch_status();
 }
