@@ -12,7 +12,9 @@ gradient is  (sum over ranks of grad(numerator_r)) / (sum over ranks of denomina
 the average of per-rank mean-loss gradients.  Each rank therefore back-propagates its local
 numerator (reduction='sum'), the numerators/denominators ride in the same all-reduce, and
 the division happens once afterwards.  The payload is ~5 MB: latency-bound, a single
-collective, no bucketing needed.
+collective, no bucketing needed.  The flat buffer is built by ONE concatenation kernel after
+backward (gradients are not accumulated into pre-attached views: that would cost one small
+add kernel per parameter per step).
 """
 import os
 
@@ -60,35 +62,32 @@ def shard_indices(perm, step, per_rank, rank, world_size):
 
 
 class FlatGradSync:
-    """Owns the flat gradient buffer; parameters' .grad are views into it."""
+    """Packs every parameter gradient plus the two loss scalars into ONE flat fp32 buffer per
+    step, all-reduces it, normalises, and hands the parameters views into it as their .grad.
+
+    Gradients are left to autograd as separate tensors (`.grad = None` before backward, so no
+    accumulate kernel runs per parameter); one concatenation kernel builds the flat buffer."""
 
     def __init__(self, params, group=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
-        self.n_grad = n
-        self.flat = torch.zeros(n + 2, dtype=torch.float32, device=dev)
-        self.group = group
-        off = 0
         for p in self.params:
             if p.dtype != torch.float32 or p.device != dev:
                 raise ValueError("FlatGradSync needs fp32 parameters on one device")
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        self.n_grad = sum(p.numel() for p in self.params)
+        self.group = group
+        self.flat = None
+        self._scalars = None
 
     def zero_grad(self):
-        """Replaces optimizer.zero_grad(): keeps the .grad views alive."""
-        self.flat.zero_()
-        off = 0
-        for p in self.params:  # re-attach in case something set a grad to None
-            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
-                p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        """Replaces optimizer.zero_grad(): drops the gradients (nothing is launched)."""
+        for p in self.params:
+            p.grad = None
 
     def weighted_ce_backward(self, logits, labels, class_weights):
-        """Back-propagate the local numerator and stash (denominator, numerator)."""
+        """Back-propagate the local numerator and keep (denominator, numerator) for the exchange."""
         if logits.is_cuda:      # fused HIP pass: numerator (with gradient) + denominator at once
             from . import ops
             num, stats = ops.weighted_cross_entropy_stats(logits, labels, class_weights)
@@ -97,16 +96,25 @@ class FlatGradSync:
             num = F.cross_entropy(logits, labels, weight=class_weights, reduction="sum")
             den = class_weights[labels].sum()
         num.backward()
-        self.flat[self.n_grad] = den.detach()
-        self.flat[self.n_grad + 1] = num.detach()
+        self._scalars = torch.stack([den.detach(), num.detach()])
 
     def all_reduce_and_normalise(self):
-        """One collective; afterwards every rank holds the exact global-batch gradient.
-        Returns the global weighted-mean loss (0-dim tensor, no host sync)."""
+        """One concatenation, one collective, one division; afterwards every rank holds the exact
+        global-batch gradient in `p.grad` (views of the flat buffer).  Returns the global
+        weighted-mean loss (0-dim tensor, no host sync)."""
+        if self._scalars is None:
+            raise RuntimeError("call weighted_ce_backward() first")
+        pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+        self.flat = torch.cat(pieces + [self._scalars.to(pieces[0].dtype)])
+        self._scalars = None
         _, w = world()
         if w > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         den = self.flat[self.n_grad]
         loss = self.flat[self.n_grad + 1] / den
         self.flat[:self.n_grad].div_(den)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
         return loss

@@ -117,9 +117,8 @@ def test_single_process_sync_is_identity():
         assert p.grad.data_ptr() == flat_ptr + 4 * off      # grads are views of the flat buffer
         assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7)
         off += p.numel()
-    # a second step accumulates into the same views after zero_grad()
-    sync.zero_grad()
-    assert all(float(p.grad.abs().max()) == 0 for p in net.parameters())
+    sync.zero_grad()                                         # gradients are dropped, nothing launched
+    assert all(p.grad is None for p in net.parameters())
 
 
 def test_shard_indices_partition():
