@@ -572,6 +572,7 @@ extern "C" int32_t gts_set_option(int32_t option, int32_t value) {
     case GTS_OPT_IGRAD_TILE: gts::g_igrad_variant = value; return GTS_OK;
     case GTS_OPT_SPMM_ROWS_PER_WAVE: gts::g_spmm_seq = value; return GTS_OK;
     case GTS_OPT_SPMM_STREAMING: gts::g_spmm_nt = value; return GTS_OK;
+    case GTS_OPT_PROJECT_STREAMING: gts::g_project_nt = value; return GTS_OK;
     case GTS_OPT_WGRAD_TILE: gts::g_wgrad_variant = value; return GTS_OK;
     default: return GTS_ERR_ARGKIND;
   }

@@ -5,10 +5,29 @@
 // (<= 32768 rows) stays in L2.  Lane l of a wave owns voxels base + j*64 + l, so every
 // store instruction writes 64 consecutive rows (1 KiB for fp32x4 logits) and the ids of a
 // 512-voxel wave tile arrive as ONE 16 B/lane load that is re-distributed through LDS.
-#include "gts_common.h"
+#include "gts_rows.h"
 
 namespace gts {
 namespace {
+
+// write-once output rows leave through non-temporal stores (they are 8x the input bytes and are
+// not read again by this kernel); g_project_nt = 0 switches back to plain stores (tuning knob)
+template <typename RowT>
+__device__ __forceinline__ void store_row(RowT* dst, const RowT& v, int nt) {
+  if (!nt) {
+    *dst = v;
+    return;
+  }
+  if constexpr (sizeof(RowT) == 16) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(*reinterpret_cast<const u4*>(&v), reinterpret_cast<u4*>(dst));
+  } else if constexpr (sizeof(RowT) == 8) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(*reinterpret_cast<const u2*>(&v), reinterpret_cast<u2*>(dst));
+  } else {
+    __builtin_nontemporal_store(v, dst);
+  }
+}
 
 constexpr int kVoxPerLane = 8;                     // one 16-byte load of int16 ids
 constexpr int kVoxPerWave = kWave * kVoxPerLane;   // 512
@@ -45,7 +64,7 @@ __device__ __forceinline__ void load_tile_ids(const int16_t* __restrict__ svs, i
 template <typename RowT>
 __global__ __launch_bounds__(kBlock) void project_rows_kernel(
     const int16_t* __restrict__ svs, const RowT* __restrict__ table,
-    const RowT* __restrict__ bg_row, RowT* __restrict__ out, int64_t n_vox, int n_rows) {
+    const RowT* __restrict__ bg_row, RowT* __restrict__ out, int64_t n_vox, int n_rows, int nt) {
   __shared__ int16_t lds[kVoxPerBlock];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
@@ -66,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void project_rows_kernel(
 #pragma unroll
     for (int j = 0; j < kVoxPerLane; ++j) {
       const int64_t i = base + j * kWave + lane;
-      if (i < n_vox) out[i] = rows[j];
+      if (i < n_vox) store_row(out + i, rows[j], nt);
     }
   }
 }
@@ -138,17 +157,17 @@ extern "C" int32_t gts_project_rows_i16(const int16_t* svs, const void* table,
     case 4:
       project_rows_kernel<uint32_t><<<grid, kBlock, 0, st>>>(
           svs, static_cast<const uint32_t*>(table), static_cast<const uint32_t*>(bg_row),
-          static_cast<uint32_t*>(out), n_vox, nr);
+          static_cast<uint32_t*>(out), n_vox, nr, g_project_nt);
       break;
     case 8:
       project_rows_kernel<uint2><<<grid, kBlock, 0, st>>>(
           svs, static_cast<const uint2*>(table), static_cast<const uint2*>(bg_row),
-          static_cast<uint2*>(out), n_vox, nr);
+          static_cast<uint2*>(out), n_vox, nr, g_project_nt);
       break;
     case 16:
       project_rows_kernel<uint4><<<grid, kBlock, 0, st>>>(
           svs, static_cast<const uint4*>(table), static_cast<const uint4*>(bg_row),
-          static_cast<uint4*>(out), n_vox, nr);
+          static_cast<uint4*>(out), n_vox, nr, g_project_nt);
       break;
     default:
       return GTS_ERR_ARGKIND;

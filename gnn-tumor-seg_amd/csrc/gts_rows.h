@@ -101,6 +101,7 @@ struct Chunk {
 // isolation but lose 0.5 % inside the training step (the next GEMM reads gx), streaming LOADS of its
 // relu_src rows cost 40 % (bit 1 of the knob): K2 keeps ordinary loads and stores.
 inline int g_spmm_seq = 0;   // rows per wave; 0 = the kernel's own default
+inline int g_project_nt = 1;  // K12: non-temporal stores of the projected rows
 inline int g_spmm_nt = -1;   // streaming stores/loads of write-once / read-once rows; -1 = default
 
 inline int pick_seq(int64_t n_rows, int rows_per_wave_step, int preferred) {

@@ -183,6 +183,7 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
 #define GTS_OPT_GEMM_TILE 1  /* forward tile variant */
 #define GTS_OPT_WGRAD_TILE 2 /* weight-gradient tile variant (-1 = automatic) */
 #define GTS_OPT_IGRAD_TILE 3 /* input-gradient tile variant */
+#define GTS_OPT_PROJECT_STREAMING 6  /* K12: non-temporal stores of the projected rows (default 1) */
 #define GTS_OPT_SPMM_ROWS_PER_WAVE 4 /* K1-K4: rows one wave walks (0 = automatic) */
 #define GTS_OPT_SPMM_STREAMING 5     /* K1/K2: bit 0 = non-temporal stores of write-once rows, bit 1 = non-temporal
                                         loads of read-once rows (K2's relu_src); -1 = per-kernel default */
