@@ -40,6 +40,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak BW (spec)
+MFMA_F32_PEAK_TFLOPS = 157.3   # same guide: dense fp32 MFMA (v_mfma_f32_32x32x2_f32) peak
 IN_FEATS = 4
 N_CLASSES = 4
 CLASS_WEIGHTS = [0.1, 1.0, 2.0, 2.0]
@@ -186,7 +187,7 @@ def main():
         raise SystemExit("bench.py needs MI355X GPUs (the HIP path has no CPU fallback)")
     device = torch.device("cuda", torch.cuda.current_device())
 
-    from gts import _lib, ops, synth
+    from gts import _lib, dense, ops, synth
     from model.gnn_model import GNN
 
     _lib.load()
@@ -202,6 +203,11 @@ def main():
 
     timer = KernelTimer()
     ops.KERNEL_TIMERS[cfg["kernel"]] = timer
+    # K11, the kernel most of the step's time is spent in: the hidden layers' forward GEMM
+    # out = h W_self^T + m W_neigh^T + b (C2/C5: N=256, K=256+256; C3: fc, N=1024, K=1024)
+    gemm_shape = (1024, 1024, 0) if args.config == "c3" else (256, 256, 256)
+    gemm_timer = KernelTimer()
+    dense.GEMM_TIMERS[gemm_shape] = gemm_timer
 
     if args.config == "c5":
         model.net.eval()
@@ -233,14 +239,14 @@ def main():
         step(i)
     fence()
     log("timed region")
-    timer.enabled = True
+    timer.enabled = gemm_timer.enabled = True
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = step(i)
     host_enqueue = time.perf_counter() - t0     # CPU time to enqueue K steps (no sync inside)
     fence()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
+    timer.enabled = gemm_timer.enabled = False
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -290,6 +296,16 @@ def main():
                          "rocprof_avg_launch_us": rocprof_us,
                          "launches_timed": len(timer.pairs)},
         }
+        gemm_ms = gemm_timer.mean_ms()
+        if gemm_ms:
+            n, k0, k1 = gemm_shape
+            flops = 2.0 * n_b * n * (k0 + k1)
+            tf = flops / (gemm_ms * 1e-3) / 1e12
+            result["roofline_mfma"] = {
+                "bound": "mfma", "kernel": f"linear_fwd [{n_b}x{k0}+{k1}] x [{n}x{k0 + k1}]^T (K11)",
+                "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "flops_per_launch": flops,
+                "avg_launch_us": round(gemm_ms * 1e3, 2), "launches_timed": len(gemm_timer.pairs)}
         if world == 1 and not args.no_cpu_baseline and args.config != "c5":
             cpu_steps = 1 if args.config == "c3" else args.cpu_steps   # a GAT step takes ~1 min on the CPU
             result["cpu_baseline"] = cpu_baseline(cfg, args.graphs_per_gpu, args.graph_kind, cpu_steps)

@@ -90,10 +90,12 @@ __global__ __launch_bounds__(kBlock) void project_rows_kernel(
   }
 }
 
+// occ (optional): [X + Y + Z] plane flags, set to 1 for every x / y / z plane that holds a voxel
+// with a non-zero (tumour) label — all writers store the same byte, so the race is benign.
 __global__ __launch_bounds__(kBlock) void project_argmax_kernel(
     const int16_t* __restrict__ svs, const float* __restrict__ logits,
     const int16_t* __restrict__ relabel, int16_t* __restrict__ out, int64_t n_vox, int n_rows,
-    int n_classes) {
+    int n_classes, uint8_t* __restrict__ occ, int dim_x, int dim_y, int dim_z) {
   __shared__ int16_t lds[kVoxPerBlock];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
@@ -116,8 +118,14 @@ __global__ __launch_bounds__(kBlock) void project_argmax_kernel(
           if (best < val) best = val, label = c;  // first maximum, like torch.max(dim=1)
         }
       }
-      if (relabel != nullptr) label = relabel[label];
       const int64_t i = base + j * kWave + lane;
+      if (occ != nullptr && label != 0 && i < n_vox) {
+        const int64_t plane = i / dim_z;
+        occ[plane / dim_y] = 1;
+        occ[dim_x + plane % dim_y] = 1;
+        occ[dim_x + dim_y + i % dim_z] = 1;
+      }
+      if (relabel != nullptr) label = relabel[label];
       if (i < n_vox) out[i] = static_cast<int16_t>(label);
     }
   }
@@ -131,7 +139,7 @@ inline unsigned stream_grid(int64_t n_vox) {
 }  // namespace
 }  // namespace gts
 
-extern "C" int32_t gts_abi_version(void) { return 4; }
+extern "C" int32_t gts_abi_version(void) { return 5; }
 
 extern "C" const char* gts_error_string(int32_t code) {
   switch (code) {
@@ -184,6 +192,25 @@ extern "C" int32_t gts_project_argmax_i16(const int16_t* svs, const float* logit
     return GTS_ERR_SHAPE;
   if (n_vox == 0) return GTS_OK;
   project_argmax_kernel<<<stream_grid(n_vox), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
-      svs, logits, relabel, out, n_vox, static_cast<int>(n_rows), static_cast<int>(n_classes));
+      svs, logits, relabel, out, n_vox, static_cast<int>(n_rows), static_cast<int>(n_classes),
+      nullptr, 1, 1, 1);
+  return launch_status();
+}
+
+extern "C" int32_t gts_project_argmax_occupancy_i16(const int16_t* svs, const float* logits,
+                                                    int16_t* out, uint8_t* occupancy,
+                                                    int64_t dim_x, int64_t dim_y, int64_t dim_z,
+                                                    int64_t n_rows, int64_t n_classes,
+                                                    void* stream) {
+  using namespace gts;
+  if (!svs || !out || !occupancy || (n_rows > 0 && !logits)) return GTS_ERR_NULL;
+  if (dim_x < 0 || dim_y < 0 || dim_z < 0 || dim_x > 32768 || dim_y > 32768 || dim_z > 32768 ||
+      n_rows < 0 || n_rows > 32768 || n_classes < 1 || n_classes > 1024)
+    return GTS_ERR_SHAPE;
+  const int64_t n_vox = dim_x * dim_y * dim_z;
+  if (n_vox == 0) return GTS_OK;
+  project_argmax_kernel<<<stream_grid(n_vox), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
+      svs, logits, nullptr, out, n_vox, static_cast<int>(n_rows), static_cast<int>(n_classes),
+      occupancy, static_cast<int>(dim_x), static_cast<int>(dim_y), static_cast<int>(dim_z));
   return launch_status();
 }

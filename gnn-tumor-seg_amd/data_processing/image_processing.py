@@ -28,6 +28,24 @@ def determine_tumor_crop(preds):
     return _any_along_other_axes(mask)
 
 
+def tumor_crop_from_plane_flags(any_x, any_y, any_z):
+    """determine_tumor_crop from the three per-axis `any` vectors of the UNdilated tumour mask
+    (what K12's occupancy variant reports).  The 6-neighbourhood dilation of the reference adds,
+    to the planes that hold tumour, exactly their two neighbours along the same axis, so the
+    crop is the 1-D dilation of each vector; no tumour at all selects the whole volume."""
+    flags = [np.asarray(v).astype(bool) for v in (any_x, any_y, any_z)]
+    if not any(f.any() for f in flags):
+        print("No GNN predicted tumor, not cropping image")
+        return np.ix_(*[np.ones(len(f), dtype=bool) for f in flags])
+    grown = []
+    for f in flags:
+        g = f.copy()
+        g[1:] |= f[:-1]
+        g[:-1] |= f[1:]
+        grown.append(g)
+    return np.ix_(*grown)
+
+
 def determine_brain_crop(multi_modal_data):
     """Box of all planes that are not entirely black (reference image_processing.py:31-42)."""
     if multi_modal_data.ndim == 4:

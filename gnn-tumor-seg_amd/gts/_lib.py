@@ -10,7 +10,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgts_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "gts_hip.h")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -33,6 +33,10 @@ SIGNATURES = {
     "gts_gat_bwd_src_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     "gts_project_rows_i16": [_p, _p, _p, _p, _i64, _i64, _i32, _p],
     "gts_project_argmax_i16": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
+    "gts_project_argmax_occupancy_i16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "gts_crop_concat_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p],
+    "gts_argmax_scatter_i16": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p],
+    "gts_label_confusion_i16": [_p, _p, _p, _i64, _p],
     "gts_linear_fwd_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p],
     "gts_linear_bwd_input_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "gts_linear_bwd_weight_workspace": [_i64, _i64, _i64, _i32],

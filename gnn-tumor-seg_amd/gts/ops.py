@@ -273,6 +273,113 @@ def project_argmax(svs, logits, relabel=None):
     return out
 
 
+def project_argmax_occupancy(svs, logits):
+    """K12 arg-max projection of a 3-D partitioning plus the tumour-plane flags of the result:
+    (int16 labels [X,Y,Z], (any over (y,z) [X], any over (x,z) [Y], any over (x,y) [Z]) as uint8)."""
+    _f32(logits)
+    if svs.dtype != torch.int16 or svs.dim() != 3:
+        raise _lib.GtsError("supervoxel partitioning must be a 3-D int16 volume")
+    svs, logits = svs.contiguous(), logits.contiguous()
+    require_device(svs, logits)
+    dx, dy, dz = svs.shape
+    out = torch.empty(svs.shape, dtype=torch.int16, device=svs.device)
+    occ = torch.zeros(dx + dy + dz, dtype=torch.uint8, device=svs.device)
+    if svs.numel():
+        check(_lib.load().gts_project_argmax_occupancy_i16(ptr(svs), ptr(logits), ptr(out), ptr(occ), dx, dy, dz,
+                                                           logits.shape[0], logits.shape[1], current_stream()),
+              "gts_project_argmax_occupancy_i16")
+    return out, (occ[:dx], occ[dx:dx + dy], occ[dx + dy:])
+
+
+class CropBox:
+    """Outer product of three ascending plane-index vectors (what np.ix_ of boolean plane masks
+    selects) inside a [X, Y, Z] volume; validated on the host, kept as int32 on the device."""
+
+    def __init__(self, xs, ys, zs, volume_shape, device):
+        import numpy as np
+
+        self.volume_shape = tuple(int(d) for d in volume_shape)
+        self.host = []
+        for idx, extent in zip((xs, ys, zs), self.volume_shape):
+            idx = np.asarray(idx).reshape(-1).astype(np.int64)
+            if idx.size and (idx.min() < 0 or idx.max() >= extent or np.any(np.diff(idx) <= 0)):
+                raise _lib.GtsError("crop indices must be strictly ascending and inside the volume")
+            self.host.append(idx)
+        self.shape = tuple(len(i) for i in self.host)
+        self.dev = [torch.from_numpy(i.astype(np.int32)).to(device) for i in self.host]
+
+    def as_ix(self):
+        import numpy as np
+
+        return np.ix_(*self.host)
+
+
+def crop_concat(img, svs, table, bg_row, box):
+    """K16.  [1, Ci + Ct, cx, cy, cz] fp32 = cat([img, table_plus_bg[svs]], -1)[box] moved to
+    channels-first, without materialising the voxel-logit volume.  img [X,Y,Z,Ci] fp32 (or None),
+    svs [X,Y,Z] int16, table [N,Ct] fp32, bg_row [Ct]."""
+    _f32(img, table, bg_row)
+    if svs.dtype != torch.int16 or tuple(svs.shape) != box.volume_shape:
+        raise _lib.GtsError("partitioning must be int16 with the crop box's volume shape")
+    ci = 0
+    if img is not None:
+        if img.dim() != 4 or tuple(img.shape[:3]) != box.volume_shape:
+            raise _lib.GtsError("image must be [X, Y, Z, C] over the same volume")
+        img, ci = img.contiguous(), img.shape[3]
+    svs, table, bg_row = svs.contiguous(), table.contiguous(), bg_row.contiguous()
+    require_device(svs, table, bg_row, img, *box.dev)
+    ct = table.shape[1]
+    if bg_row.numel() != ct:
+        raise _lib.GtsError("background row does not match table rows")
+    cx, cy, cz = box.shape
+    out = torch.empty((1, ci + ct, cx, cy, cz), dtype=torch.float32, device=svs.device)
+    if out.numel():
+        check(_lib.load().gts_crop_concat_f32(ptr(img), ptr(svs), ptr(table), ptr(bg_row), ptr(box.dev[0]),
+                                              ptr(box.dev[1]), ptr(box.dev[2]), ptr(out), cx, cy, cz,
+                                              box.volume_shape[1], box.volume_shape[2], table.shape[0], ci, ct,
+                                              current_stream()), "gts_crop_concat_f32")
+    return out
+
+
+def argmax_scatter(scores, box, relabel=None):
+    """K17.  int16 [X,Y,Z] volume, zero outside the box, arg-max over channels of
+    scores [C, cx, cy, cz] (or [1, C, ...]) inside."""
+    _f32(scores)
+    if scores.dim() == 5 and scores.shape[0] == 1:
+        scores = scores[0]
+    if scores.dim() != 4 or tuple(scores.shape[1:]) != box.shape:
+        raise _lib.GtsError("scores must be [C, cx, cy, cz] over the crop box")
+    scores = scores.contiguous()
+    require_device(scores, relabel, *box.dev)
+    if relabel is not None and (relabel.dtype != torch.int16 or relabel.numel() < scores.shape[0]):
+        raise _lib.GtsError("relabel must be int16 with one entry per class")
+    out = torch.zeros(box.volume_shape, dtype=torch.int16, device=scores.device)
+    cx, cy, cz = box.shape
+    if scores.numel():
+        check(_lib.load().gts_argmax_scatter_i16(ptr(scores), ptr(relabel), ptr(box.dev[0]), ptr(box.dev[1]),
+                                                 ptr(box.dev[2]), ptr(out), cx, cy, cz, box.volume_shape[1],
+                                                 box.volume_shape[2], scores.shape[0], current_stream()),
+              "gts_argmax_scatter_i16")
+    return out
+
+
+def label_confusion(pred, truth):
+    """K15.  int64 [5, 5] table on the device: entry [cp, ct] counts the positions where the
+    predicted label has class cp and the true label class ct (class = label for 0..3, 4 for
+    anything else).  pred / truth: int16 tensors of equal size."""
+    if pred.dtype != torch.int16 or truth.dtype != torch.int16:
+        raise _lib.GtsError("label_confusion takes int16 labels")
+    if pred.numel() != truth.numel():
+        raise _lib.GtsError(f"label_confusion: {pred.numel()} predictions vs {truth.numel()} labels")
+    pred, truth = pred.contiguous(), truth.contiguous()
+    require_device(pred, truth)
+    counts = torch.zeros((5, 5), dtype=torch.int64, device=pred.device)
+    if pred.numel():
+        check(_lib.load().gts_label_confusion_i16(ptr(pred), ptr(truth), ptr(counts), pred.numel(),
+                                                  current_stream()), "gts_label_confusion_i16")
+    return counts
+
+
 # ---------------------------------------------------------------- class-weighted cross-entropy
 class _WeightedCE(torch.autograd.Function):
     """(logits [N,C], labels int64 [N], class_w [C] or None) -> stats = [num, den, num/den]."""

@@ -33,6 +33,36 @@ def calculate_dice_from_logical_array(binary_predictions, binary_ground_truth):
     return (2 * tp) / (2 * tp + fp + fn)
 
 
+def _region_members(n_classes=5):
+    """Class-index sets of WT / CT / ET over the 5 classes of a gts.ops.label_confusion table
+    (0..3 = the labels, 4 = any other value: tumour for WT's `!= 0`, outside CT and ET)."""
+    return ([c for c in range(n_classes) if c != HEALTHY], [NET, ET], [ET])
+
+
+def dices_from_confusion(confusion):
+    """[WT, CT, ET] Dice from a [5, 5] coincidence table (rows: predicted class, columns: true
+    class).  Same integers tp / fp / fn as calculate_dice_from_logical_array counts on the
+    binarised arrays, hence the same quotient."""
+    m = np.asarray(confusion, dtype=np.int64)
+    dices = []
+    for members in _region_members(m.shape[0]):
+        inside = np.zeros(m.shape[0], dtype=bool)
+        inside[members] = True
+        tp = int(m[np.ix_(inside, inside)].sum())
+        fp = int(m[np.ix_(inside, ~inside)].sum())
+        fn = int(m[np.ix_(~inside, inside)].sum())
+        dices.append(1 if tp + fp + fn == 0 else (2 * tp) / (2 * tp + fp + fn))
+    return dices
+
+
+def label_counts_from_confusion(confusion):
+    """count_node_labels(preds) ++ count_node_labels(labels) from the coincidence table."""
+    m = np.asarray(confusion, dtype=np.int64)
+    if m[4].sum() or m[:, 4].sum():
+        raise IndexError("labels outside 0..3 (count_node_labels indexes a 4-entry table)")
+    return np.concatenate([m[:4, :4].sum(axis=1), m[:4, :4].sum(axis=0)]).astype(np.float64)
+
+
 def calculate_node_dices(preds, labels):
     return [calculate_dice_from_logical_array(p, g) for p, g in zip(_regions(preds), _regions(labels))]
 
@@ -63,6 +93,12 @@ def calculate_hd95_from_logical_array(pred, gt):
         return hd95(pred, gt)
     except RuntimeError:
         return 0 if (1 not in pred and 1 not in gt) else 300
+
+
+def calculate_hd95s(predicted_voxels, true_voxels):
+    """[WT, CT, ET] HD95 for one volume (the host half of calculate_brats_metrics)."""
+    return [calculate_hd95_from_logical_array(p, g)
+            for p, g in zip(_regions(predicted_voxels), _regions(true_voxels))]
 
 
 def calculate_brats_metrics(predicted_voxels, true_voxels):

@@ -122,26 +122,42 @@ class GNN:
         metrics, then voxel metrics after projecting the predictions onto the supervoxel
         partitioning (reference :51-87).  Returns (mean of the [n,10] metric rows, sum of the
         [n,8] label-count rows); metric columns: loss | node Dice WT,CT,ET | voxel Dice WT,CT,ET |
-        voxel HD95 WT,CT,ET."""
+        voxel HD95 WT,CT,ET.
+
+        Everything up to the Dice quotients stays on the GPU: arg-max + projection is one K12
+        pass, the node- and voxel-level label coincidences are counted by K15, and only the two
+        5x5 integer tables, the loss and the predicted volume (for the scipy distance transforms
+        of HD95) travel to the host.  The integers are the ones the reference counts with numpy
+        masks, so every metric is the same double."""
         assert dataset.dataset.read_label == True  # noqa: E712
         self.net.eval()
+        source = dataset.dataset        # Subset -> underlying ImageGraphDataset
         metric_rows, count_rows = [], []
         for mri_id, graph, feats, labels in dataset:
             graph, feats, labels = self._to_device(graph, feats, labels)
+            partitioning = torch.from_numpy(source.get_supervoxel_partitioning(mri_id)).to(self.device)
+            true_voxels = source.get_voxel_labels(mri_id)
             with torch.no_grad():
                 logits = self.net(graph, feats)
                 loss = self.loss_fcn(logits, labels)
                 predicted = torch.max(logits, dim=1)[1]
-            counts, scores = self.calculate_all_metrics_for_brain(
-                mri_id, dataset, predicted.cpu().numpy(), labels.cpu().numpy())
-            metric_rows.append(np.concatenate([[loss.item()], scores]))
-            count_rows.append(counts)
+                node_table = gops.label_confusion(predicted.to(torch.int16), labels.to(torch.int16))
+                predicted_voxels = gops.project_argmax(partitioning, logits)          # K12 + arg-max
+                voxel_table = gops.label_confusion(                                  # K15
+                    predicted_voxels, torch.from_numpy(true_voxels).to(self.device).contiguous())
+            tables = torch.stack([node_table, voxel_table]).cpu().numpy()
+            hd95s = evaluation.calculate_hd95s(predicted_voxels.cpu().numpy(), true_voxels)
+            metric_rows.append(np.concatenate([[loss.item()], evaluation.dices_from_confusion(tables[0]),
+                                               evaluation.dices_from_confusion(tables[1]), hd95s]))
+            count_rows.append(evaluation.label_counts_from_confusion(tables[0]))
         metrics = np.array(metric_rows).reshape(len(metric_rows), 10)
         counts = np.array(count_rows).reshape(len(count_rows), 8)
         return np.mean(metrics, axis=0), np.sum(counts, axis=0)
 
     def calculate_all_metrics_for_brain(self, mri_id, dataset, node_preds, node_labels):
-        """(label counts [pred x4, truth x4], [node Dice x3, voxel Dice x3, voxel HD95 x3])."""
+        """(label counts [pred x4, truth x4], [node Dice x3, voxel Dice x3, voxel HD95 x3]) from
+        host arrays of node predictions / labels — the reference's helper (:76-87), kept for its
+        callers; `evaluate` computes the same numbers from device-side counts."""
         source = dataset.dataset        # Subset -> underlying ImageGraphDataset
         label_counts = np.concatenate([evaluation.count_node_labels(node_preds),
                                        evaluation.count_node_labels(node_labels)])

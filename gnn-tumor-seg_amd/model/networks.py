@@ -62,6 +62,23 @@ class GAT(nn.Module):
         return self.layers[-1](g, h).mean(1)
 
 
+class CnnRefinementNet(nn.Module):
+    """Two 5x5x5 replicate-padded Conv3d layers with a ReLU in between, refining
+    [1, in_feats, x, y, z] (image modalities ++ GNN voxel logits) into class scores
+    (reference: model/networks.py:84-94; checkpoint keys `conv_layers.{0,1}.{weight,bias}`).
+    Dense convolution is vendor-library territory: it runs on MIOpen through torch."""
+
+    def __init__(self, in_feats, out_classes, layer_sizes):
+        super().__init__()
+        widths = [in_feats, layer_sizes[0], out_classes]
+        self.conv_layers = nn.ModuleList(
+            nn.Conv3d(in_channels=a, out_channels=b, kernel_size=5, stride=1, padding=2, padding_mode="replicate")
+            for a, b in zip(widths[:-1], widths[1:]))
+
+    def forward(self, comb_img_logits):
+        return self.conv_layers[1](F.relu(self.conv_layers[0](comb_img_logits)))
+
+
 def init_graph_net(model_type, hp):
     """'GSpool' | 'GSgcn' | 'GSmean' | 'GAT' -> module (reference: model/networks.py:68-81).
     `hp` is a FullParamSet / EvalParamSet; feature dropout only exists on the former and is

@@ -135,6 +135,52 @@ int32_t gts_project_argmax_i16(const int16_t* svs, const float* logits, const in
                                int16_t* out, int64_t n_vox, int64_t n_rows, int64_t n_classes,
                                void* stream);
 
+/* gts_project_argmax_i16 over a [dim_x, dim_y, dim_z] partitioning that also reports which
+ * planes hold tumour: occupancy is a caller-zeroed uint8[dim_x + dim_y + dim_z]; byte x,
+ * dim_x + y, dim_x + dim_y + z is set to 1 when some voxel of that plane gets a non-zero
+ * label.  These are `mask.any(axis=...)` of determine_tumor_crop (data_processing/
+ * image_processing.py:8-17, reached from scripts/generate_joint_predictions.py:66) before its
+ * one-voxel dilation, which the host applies to the three vectors. */
+int32_t gts_project_argmax_occupancy_i16(const int16_t* svs, const float* logits, int16_t* out,
+                                         uint8_t* occupancy, int64_t dim_x, int64_t dim_y,
+                                         int64_t dim_z, int64_t n_rows, int64_t n_classes,
+                                         void* stream);
+
+/* ---- K16/K17: glue between the GNN and the refinement CNN -----------------------------------
+ * Replace the tensor indexing of predict_one_sample (scripts/generate_joint_predictions.py:
+ * 59-73) and combine_logits_and_image (model/cnn_model.py:85-88).  A crop is the outer product
+ * of three ascending index vectors xs [cx], ys [cy], zs [cz] (np.ix_ of boolean plane masks),
+ * int32 on the device, into a volume whose two inner extents are dim_y, dim_z.
+ *
+ * crop_concat: out[c, i, j, k] (fp32, [img_channels + row_channels, cx, cy, cz] contiguous)
+ *   = img[xs[i], ys[j], zs[k], c]                         for c <  img_channels
+ *   = table_plus_bg[svs[xs[i], ys[j], zs[k]]][c - img_channels]   otherwise,
+ *   table [n_rows, row_channels] node logits, bg_row the background logits (id -1), img
+ *   [X, Y, Z, img_channels] channels-last.  Exact copies. */
+int32_t gts_crop_concat_f32(const float* img, const int16_t* svs, const float* table,
+                            const float* bg_row, const int32_t* xs, const int32_t* ys,
+                            const int32_t* zs, float* out, int64_t cx, int64_t cy, int64_t cz,
+                            int64_t dim_y, int64_t dim_z, int64_t n_rows, int64_t img_channels,
+                            int64_t row_channels, void* stream);
+/* argmax_scatter: out[xs[i], ys[j], zs[k]] = argmax_c scores[c, i, j, k] (first maximum, as
+ * torch.argmax; optional relabel table), scores [n_classes, cx, cy, cz]; the other voxels of the
+ * caller-zeroed int16 volume `out` are left alone. */
+int32_t gts_argmax_scatter_i16(const float* scores, const int16_t* relabel, const int32_t* xs,
+                               const int32_t* ys, const int32_t* zs, int16_t* out, int64_t cx,
+                               int64_t cy, int64_t cz, int64_t dim_y, int64_t dim_z,
+                               int64_t n_classes, void* stream);
+
+/* ---- K15: label coincidence counts for the Dice metrics -------------------------------------
+ * Replaces the numpy mask arithmetic of model/evaluation.py:24-46 (count_node_labels,
+ * calculate_node_dices), :64-79 (voxel Dice in calculate_brats_metrics) and :98-106
+ * (calculate_dice_from_logical_array) reached from GNN.evaluate, model/gnn_model.py:76-87.
+ * counts[5*cp + ct] += #{ i : class(pred[i]) == cp and class(truth[i]) == ct }, where
+ * class(v) = v for 0..3 and 4 for any other value.  counts is a caller-owned int64[25] on the
+ * device that the call ADDS to (zero it first); integer atomics, so the result is exact and
+ * independent of scheduling. */
+int32_t gts_label_confusion_i16(const int16_t* pred, const int16_t* truth, int64_t* counts,
+                                int64_t n, void* stream);
+
 /* ---- K11: dense fp32 layer GEMMs on the matrix cores -------------------------------------
  * Replace the nn.Linear calls inside DGL's SAGEConv / GATConv (fc_pool, fc_self + fc_neigh,
  * fc; reached from model/networks.py:25,28,30,46,52,56) and their autograd.  Exact fp32

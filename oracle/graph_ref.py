@@ -122,3 +122,15 @@ def swap_labels_to_brats_ref(preds):
     out[preds == 1] = 2
     out[preds == 2] = 1
     return out
+
+
+def label_confusion_ref(pred, truth):
+    """int64 [5, 5] coincidence table of two integer label arrays: entry [cp, ct] counts the
+    positions with class(pred) == cp and class(truth) == ct, class(v) = v for 0..3, else 4.
+    (The integers behind /root/reference/model/evaluation.py:24-46,64-79,98-106: every mask
+    there is a union of these classes.)"""
+    p = np.asarray(pred).ravel().astype(np.int64)
+    t = np.asarray(truth).ravel().astype(np.int64)
+    cp = np.where((p >= 0) & (p <= 3), p, 4)
+    ct = np.where((t >= 0) & (t <= 3), t, 4)
+    return np.bincount(5 * cp + ct, minlength=25).reshape(5, 5).astype(np.int64)

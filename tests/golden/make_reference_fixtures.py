@@ -3,7 +3,8 @@
 Run in the build container only (needs /root/reference):   python tests/golden/make_reference_fixtures.py
 Writes data files (inputs + expected outputs) next to this script; no reference source is
 copied.  Importable reference modules: data_processing.graph_io,
-utils.hyperparam_helpers, utils.training_helpers, model.evaluation (the last one needs the
+utils.hyperparam_helpers, utils.training_helpers, data_processing.image_processing,
+model.evaluation (the last one needs the
 `np.bool` alias that NumPy 2 removed: added here as an environment shim, the reference file
 is untouched).  Everything that imports dgl / nibabel is NOT importable and is not used.
 """
@@ -22,6 +23,7 @@ if not hasattr(np, "bool"):
     np.bool = bool  # environment shim for model/evaluation.py:170 under NumPy 2
 
 from data_processing import graph_io as ref_graph_io          # noqa: E402
+from data_processing import image_processing as ref_img       # noqa: E402
 from model import evaluation as ref_eval                      # noqa: E402
 from utils import hyperparam_helpers as ref_hp                # noqa: E402
 from utils import training_helpers as ref_th                  # noqa: E402
@@ -131,9 +133,43 @@ def evaluation_fixture():
     np.savez_compressed(os.path.join(OUT, "ref_evaluation.npz"), **cases)
 
 
+def tumor_crop_fixture():
+    """determine_tumor_crop on label volumes: one blob, tumour on the border, two separated
+    blobs (gaps in the selected planes), isolated voxels, nothing predicted."""
+    rng = np.random.default_rng(4242)
+    shape = (18, 15, 13)
+    volumes = []
+    v = np.zeros(shape, dtype=np.int64)
+    v[5:9, 4:7, 6:8] = 2
+    volumes.append(v)
+    v = np.zeros(shape, dtype=np.int64)
+    v[0:2, 12:15, 0] = 1
+    v[17, 0, 12] = 3
+    volumes.append(v)
+    v = np.zeros(shape, dtype=np.int64)
+    v[2:4, 2:4, 2:4] = 1
+    v[10:13, 9:11, 8:11] = 3
+    volumes.append(v)
+    v = (rng.random(shape) < 0.004).astype(np.int64) * rng.integers(1, 4, shape)
+    volumes.append(v)
+    volumes.append(np.zeros(shape, dtype=np.int64))
+    cases = {}
+    with redirect_stdout(io.StringIO()):
+        for i, vol in enumerate(volumes):
+            ix = ref_img.determine_tumor_crop(vol)
+            cases[f"preds{i}"] = vol.astype(np.int16)
+            for name, idx in zip("xyz", ix):
+                cases[f"{name}{i}"] = np.asarray(idx).reshape(-1).astype(np.int64)
+    np.savez_compressed(os.path.join(OUT, "ref_tumor_crop.npz"), **cases)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["tumor_crop"]:      # add this one fixture without touching the others
+        tumor_crop_fixture()
+        sys.exit(0)
     scatter_fixture()
     hyperparam_fixture()
     training_fixture()
     evaluation_fixture()
+    tumor_crop_fixture()
     print("fixtures written to", OUT)

@@ -67,3 +67,37 @@ def test_train_and_predict_cli(tmp_path, monkeypatch):
         assert np.array_equal(pred, graph_ref.swap_labels_to_brats_ref(want))
     with pytest.raises(ValueError):
         gen.save_predictions(net, ds, "bogus")
+
+
+def test_evaluate_on_device_counts_equal_the_host_route(tmp_path):
+    """GNN.evaluate (arg-max + projection in K12, coincidence tables in K15, Dice from the
+    tables) returns exactly what the reference-shaped host helper computes from the same
+    predictions with numpy masks."""
+    from data_processing.data_loader import ImageGraphDataset
+    from model.gnn_model import GNN
+    from utils.hyperparam_helpers import FullParamSet
+
+    data = str(tmp_path / "data") + "/"
+    write_dataset(data, 4)
+    with redirect_stdout(io.StringIO()):
+        ds = ImageGraphDataset(data, "BraTS_", read_image=False, read_graph=True, read_label=True)
+        hp = FullParamSet(3, 20, 4, 5e-3, 0.98, 1e-4, [0.1, 1, 2, 2], [64, 64], 0, None, None)
+        torch.manual_seed(0)
+        model = GNN("GSpool", hp, ds, batch_size=2)
+    for _ in range(3):
+        model.run_epoch()
+    subset = torch.utils.data.Subset(ds, [0, 1, 2, 3])
+    metrics, counts = model.evaluate(subset)
+    rows, count_rows = [], []
+    for mri_id, graph, feats, labels in subset:
+        with torch.no_grad():
+            logits = model.net(graph.to("cuda"), torch.FloatTensor(feats).to("cuda"))
+            loss = model.loss_fcn(logits, torch.LongTensor(labels).to("cuda"))
+        c, m = model.calculate_all_metrics_for_brain(mri_id, subset, logits.argmax(1).cpu().numpy(),
+                                                     np.asarray(labels))
+        rows.append(np.concatenate([[loss.item()], m]))
+        count_rows.append(c)
+    assert metrics.shape == (10,) and counts.shape == (8,)
+    assert np.array_equal(metrics, np.mean(np.array(rows), axis=0))
+    assert np.array_equal(counts, np.sum(np.array(count_rows), axis=0))
+    assert len(set(np.concatenate(count_rows)[:4] > 0)) >= 1 and counts[4:].sum() == sum(len(s[3]) for s in subset)

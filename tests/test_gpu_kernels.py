@@ -201,6 +201,49 @@ def test_projection_unaligned_view_and_empty():
 
 
 # ------------------------------------------------------------------ full-size properties (C2 / C5)
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 1000, 2049, 100003])
+def test_label_confusion_bit_exact(n):
+    rng = np.random.default_rng(n)
+    pred = rng.integers(-3, 8, n).astype(np.int16)
+    true = rng.choice(np.array([0, 1, 2, 3, 4, -1, 32767, -32768], dtype=np.int16), n)
+    got = ops.label_confusion(torch.from_numpy(pred).to(DEV), torch.from_numpy(true).to(DEV))
+    assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), graph_ref.label_confusion_ref(pred, true))
+
+
+def test_label_confusion_unaligned_views_and_errors():
+    rng = np.random.default_rng(5)
+    pred = torch.from_numpy(rng.integers(0, 4, 5003).astype(np.int16)).to(DEV)
+    true = torch.from_numpy(rng.integers(0, 4, 5003).astype(np.int16)).to(DEV)
+    for a, b in ((1, 0), (0, 3), (5, 5)):        # 2-byte-aligned starts: the scalar path
+        p, t = pred[a:a + 4990], true[b:b + 4990]
+        want = graph_ref.label_confusion_ref(p.cpu().numpy(), t.cpu().numpy())
+        assert np.array_equal(ops.label_confusion(p, t).cpu().numpy(), want)
+    with pytest.raises(gts.GtsError):
+        ops.label_confusion(pred, true[:-1])
+    with pytest.raises(gts.GtsError):
+        ops.label_confusion(pred.int(), true.int())
+
+
+def test_label_confusion_reference_fixture_and_full_size(golden_dir):
+    from model import evaluation
+
+    fx = np.load(os.path.join(golden_dir, "ref_evaluation.npz"))
+    for i in range(3):
+        pred, true = fx[f"pred{i}"].astype(np.int16), fx[f"true{i}"].astype(np.int16)
+        table = ops.label_confusion(torch.from_numpy(pred).to(DEV), torch.from_numpy(true).to(DEV)).cpu().numpy()
+        assert np.array_equal(np.array(evaluation.dices_from_confusion(table), dtype=np.float64), fx[f"brats{i}"][:3])
+        assert np.array_equal(evaluation.label_counts_from_confusion(table)[:4], fx[f"counts{i}"])
+    # C5-sized volume: 240^3 voxels, predictions projected from node arg-max
+    svs = torch.from_numpy(synth.supervoxel_volume((240, 240, 240), cube=10, shell=20)).to(DEV)
+    rng = np.random.default_rng(1)
+    logits = torch.from_numpy(rng.standard_normal((15000, 4)).astype(np.float32)).to(DEV)
+    truth = torch.from_numpy(rng.choice(4, size=240 ** 3, p=[0.85, 0.07, 0.05, 0.03]).astype(np.int16)).to(DEV)
+    vox = ops.project_argmax(svs, logits)
+    table = ops.label_confusion(vox, truth.view(240, 240, 240)).cpu().numpy()
+    assert table.sum() == 240 ** 3
+    assert np.array_equal(table, graph_ref.label_confusion_ref(vox.cpu().numpy(), truth.cpu().numpy()))
+
+
 def test_full_size_max_properties_c2():
     """N_b = 60 000, F = 256 (4 lattice graphs): checked against torch's own GPU reducers."""
     g = gts.batch([synth.lattice_graph() for _ in range(4)]).to(DEV)

@@ -118,6 +118,55 @@ def test_evaluation_matches_reference(golden_dir):
         assert np.array_equal(evaluation.count_node_labels(pred.ravel()), fx[f"counts{i}"])
 
 
+def test_confusion_table_route_matches_reference(golden_dir):
+    """The Dice numbers GNN.evaluate derives from 5x5 coincidence tables (counted on the GPU by
+    K15, here by the numpy oracle) are the reference's, on the reference's own outputs."""
+    from model import evaluation
+
+    fx = np.load(os.path.join(golden_dir, "ref_evaluation.npz"))
+    for i in range(3):
+        table = graph_ref.label_confusion_ref(fx[f"pred{i}"], fx[f"true{i}"])
+        dices = np.array(evaluation.dices_from_confusion(table), dtype=np.float64)
+        assert np.array_equal(dices, fx[f"brats{i}"][:3]) and np.array_equal(dices, fx[f"node_dice{i}"])
+        counts = evaluation.label_counts_from_confusion(table)
+        assert np.array_equal(counts[:4], fx[f"counts{i}"])
+        assert np.array_equal(counts[4:], evaluation.count_node_labels(fx[f"true{i}"].ravel()))
+        hds = np.array(evaluation.calculate_hd95s(fx[f"pred{i}"], fx[f"true{i}"]), dtype=np.float64)
+        assert np.array_equal(hds, fx[f"brats{i}"][3:])
+    # labels outside 0..3: whole tumour for `!= 0`, outside CT / ET; count_node_labels has no slot
+    rng = np.random.default_rng(0)
+    pred, true = rng.integers(-2, 7, 5000), rng.integers(-2, 7, 5000)
+    table = graph_ref.label_confusion_ref(pred, true)
+    assert table.sum() == 5000
+    assert evaluation.dices_from_confusion(table) == evaluation.calculate_node_dices(pred, true)
+    with pytest.raises(IndexError):
+        evaluation.label_counts_from_confusion(table)
+    assert evaluation.dices_from_confusion(np.zeros((5, 5), dtype=np.int64)) == [1, 1, 1]
+
+
+def test_tumor_crop_matches_reference(golden_dir):
+    """determine_tumor_crop three ways — the host mirror, the oracle restatement, and the route
+    the joint predictor takes (per-axis `any` of the undilated mask, as K12 reports them, then
+    1-D dilation) — against the reference's own outputs."""
+    from data_processing import image_processing
+    from oracle import joint_ref
+
+    fx = np.load(os.path.join(golden_dir, "ref_tumor_crop.npz"))
+    for i in range(5):
+        preds = fx[f"preds{i}"]
+        want = [fx[f"{a}{i}"] for a in "xyz"]
+        mask = preds != 0
+        flags = (mask.any(axis=(1, 2)), mask.any(axis=(0, 2)), mask.any(axis=(0, 1)))
+        with redirect_stdout(io.StringIO()):
+            routes = (image_processing.determine_tumor_crop(preds), joint_ref.determine_tumor_crop_ref(preds),
+                      image_processing.tumor_crop_from_plane_flags(*flags))
+        for ix in routes:
+            assert [a.shape for a in ix] == [(len(want[0]), 1, 1), (1, len(want[1]), 1), (1, 1, len(want[2]))]
+            assert all(np.array_equal(np.asarray(a).reshape(-1), w) for a, w in zip(ix, want)), i
+    assert len(fx["x4"]) == 18 and len(fx["y4"]) == 15 and len(fx["z4"]) == 13      # nothing predicted: whole volume
+    assert np.any(np.diff(fx["x2"]) > 1)                                           # separated blobs leave gaps
+
+
 def test_label_maps():
     from data_processing import labels
 
