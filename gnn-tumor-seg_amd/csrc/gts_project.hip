@@ -90,8 +90,37 @@ __global__ __launch_bounds__(kBlock) void project_rows_kernel(
   }
 }
 
+// labels of this wave's tile, lane l holding voxels j*64 + l -> out, as ONE 16 B/lane store
+// (the inverse of load_tile_ids' redistribution), falling back to 2-byte stores on a ragged or
+// unaligned tile.
+__device__ __forceinline__ void store_tile_labels(int16_t* __restrict__ out, int64_t tile_base,
+                                                  int64_t n_vox, int16_t* lds_wave,
+                                                  const int (&labels)[kVoxPerLane]) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t mine = tile_base + static_cast<int64_t>(lane) * kVoxPerLane;
+  // wave-uniform: the whole tile is inside the volume and its first voxel is 16-byte aligned
+  const bool wide = tile_base + kVoxPerWave <= n_vox &&
+                    (reinterpret_cast<uintptr_t>(out + tile_base) & 15) == 0;
+  if (wide) {
+#pragma unroll
+    for (int j = 0; j < kVoxPerLane; ++j) lds_wave[j * kWave + lane] = static_cast<int16_t>(labels[j]);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    *reinterpret_cast<uint4*>(out + mine) = *reinterpret_cast<const uint4*>(lds_wave + lane * kVoxPerLane);
+    __builtin_amdgcn_wave_barrier();
+  } else {
+#pragma unroll
+    for (int j = 0; j < kVoxPerLane; ++j) {
+      const int64_t i = tile_base + j * kWave + lane;
+      if (i < n_vox) out[i] = static_cast<int16_t>(labels[j]);
+    }
+  }
+}
+
 // occ (optional): [X + Y + Z] plane flags, set to 1 for every x / y / z plane that holds a voxel
 // with a non-zero (tumour) label — all writers store the same byte, so the race is benign.
+// CLASSES = 4 reads a node's logits as one 16-byte row; 0 = runtime class count.
+template <int CLASSES>
 __global__ __launch_bounds__(kBlock) void project_argmax_kernel(
     const int16_t* __restrict__ svs, const float* __restrict__ logits,
     const int16_t* __restrict__ relabel, int16_t* __restrict__ out, int64_t n_vox, int n_rows,
@@ -106,34 +135,57 @@ __global__ __launch_bounds__(kBlock) void project_argmax_kernel(
     const int64_t base = tile * kVoxPerWave;
     int ids[kVoxPerLane];
     load_tile_ids(svs, base, n_vox, lds_wave, ids);
+    int labels[kVoxPerLane];
 #pragma unroll
     for (int j = 0; j < kVoxPerLane; ++j) {
       const int r = resolve_row(ids[j], n_rows);
       int label = 0;  // background voxels are healthy (graph_io.py:22-23)
       if (r != n_rows) {
-        const float* row = logits + static_cast<size_t>(r) * n_classes;
-        float best = row[0];
-        for (int c = 1; c < n_classes; ++c) {
-          const float val = row[c];
-          if (best < val) best = val, label = c;  // first maximum, like torch.max(dim=1)
+        if constexpr (CLASSES == 4) {
+          const float4 row = reinterpret_cast<const float4*>(logits)[r];
+          float best = row.x;  // first maximum, like torch.max(dim=1)
+          if (best < row.y) best = row.y, label = 1;
+          if (best < row.z) best = row.z, label = 2;
+          if (best < row.w) label = 3;
+        } else {
+          const float* row = logits + static_cast<size_t>(r) * n_classes;
+          float best = row[0];
+          for (int c = 1; c < n_classes; ++c) {
+            const float val = row[c];
+            if (best < val) best = val, label = c;
+          }
         }
       }
-      const int64_t i = base + j * kWave + lane;
-      if (occ != nullptr && label != 0 && i < n_vox) {
-        const int64_t plane = i / dim_z;
-        occ[plane / dim_y] = 1;
-        occ[dim_x + plane % dim_y] = 1;
-        occ[dim_x + dim_y + i % dim_z] = 1;
+      if (occ != nullptr && label != 0) {
+        const unsigned i = static_cast<unsigned>(base) + j * kWave + lane;  // n_vox < 2^31 here
+        if (i < n_vox) {
+          const unsigned plane = i / static_cast<unsigned>(dim_z);
+          occ[plane / static_cast<unsigned>(dim_y)] = 1;
+          occ[dim_x + plane % static_cast<unsigned>(dim_y)] = 1;
+          occ[dim_x + dim_y + i % static_cast<unsigned>(dim_z)] = 1;
+        }
       }
-      if (relabel != nullptr) label = relabel[label];
-      if (i < n_vox) out[i] = static_cast<int16_t>(label);
+      labels[j] = relabel != nullptr ? relabel[label] : label;
     }
+    store_tile_labels(out, base, n_vox, lds_wave, labels);
   }
 }
 
 inline unsigned stream_grid(int64_t n_vox) {
   const int64_t blocks = (n_vox + kVoxPerBlock - 1) / kVoxPerBlock;
   return static_cast<unsigned>(blocks < 4096 ? (blocks > 0 ? blocks : 1) : 4096);
+}
+
+inline void launch_project_argmax(const int16_t* svs, const float* logits, const int16_t* relabel,
+                                  int16_t* out, int64_t n_vox, int n_rows, int n_classes,
+                                  uint8_t* occ, int dx, int dy, int dz, hipStream_t st) {
+  const unsigned grid = stream_grid(n_vox);
+  if (n_classes == 4 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0)
+    project_argmax_kernel<4><<<grid, kBlock, 0, st>>>(svs, logits, relabel, out, n_vox, n_rows, 4,
+                                                      occ, dx, dy, dz);
+  else
+    project_argmax_kernel<0><<<grid, kBlock, 0, st>>>(svs, logits, relabel, out, n_vox, n_rows,
+                                                      n_classes, occ, dx, dy, dz);
 }
 
 }  // namespace
@@ -191,9 +243,9 @@ extern "C" int32_t gts_project_argmax_i16(const int16_t* svs, const float* logit
   if (n_vox < 0 || n_rows < 0 || n_rows > 32768 || n_classes < 1 || n_classes > 1024)
     return GTS_ERR_SHAPE;
   if (n_vox == 0) return GTS_OK;
-  project_argmax_kernel<<<stream_grid(n_vox), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
-      svs, logits, relabel, out, n_vox, static_cast<int>(n_rows), static_cast<int>(n_classes),
-      nullptr, 1, 1, 1);
+  launch_project_argmax(svs, logits, relabel, out, n_vox, static_cast<int>(n_rows),
+                        static_cast<int>(n_classes), nullptr, 1, 1, 1,
+                        static_cast<hipStream_t>(stream));
   return launch_status();
 }
 
@@ -208,9 +260,11 @@ extern "C" int32_t gts_project_argmax_occupancy_i16(const int16_t* svs, const fl
       n_rows < 0 || n_rows > 32768 || n_classes < 1 || n_classes > 1024)
     return GTS_ERR_SHAPE;
   const int64_t n_vox = dim_x * dim_y * dim_z;
+  if (n_vox >= (1LL << 31)) return GTS_ERR_SHAPE;  // plane arithmetic is 32-bit
   if (n_vox == 0) return GTS_OK;
-  project_argmax_kernel<<<stream_grid(n_vox), kBlock, 0, static_cast<hipStream_t>(stream)>>>(
-      svs, logits, nullptr, out, n_vox, static_cast<int>(n_rows), static_cast<int>(n_classes),
-      occupancy, static_cast<int>(dim_x), static_cast<int>(dim_y), static_cast<int>(dim_z));
+  launch_project_argmax(svs, logits, nullptr, out, n_vox, static_cast<int>(n_rows),
+                        static_cast<int>(n_classes), occupancy, static_cast<int>(dim_x),
+                        static_cast<int>(dim_y), static_cast<int>(dim_z),
+                        static_cast<hipStream_t>(stream));
   return launch_status();
 }

@@ -36,7 +36,8 @@ SIGNATURES = {
     "gts_project_argmax_occupancy_i16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "gts_crop_concat_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p],
     "gts_argmax_scatter_i16": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p],
-    "gts_label_confusion_i16": [_p, _p, _p, _i64, _p],
+    "gts_label_confusion_workspace": [_i64],
+    "gts_label_confusion_i16": [_p, _p, _p, _p, _i64, _i64, _p],
     "gts_linear_fwd_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p],
     "gts_linear_bwd_input_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "gts_linear_bwd_weight_workspace": [_i64, _i64, _i64, _i32],
@@ -46,7 +47,8 @@ SIGNATURES = {
     "gts_weighted_ce_f32": [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p],
 }
 _RESTYPE = {"gts_error_string": ctypes.c_char_p, "gts_linear_bwd_weight_workspace": _i64,
-            "gts_weighted_ce_workspace": _i64, "gts_gat_reduce_workspace": _i64}
+            "gts_weighted_ce_workspace": _i64, "gts_gat_reduce_workspace": _i64,
+            "gts_label_confusion_workspace": _i64}
 
 _lib = None
 

@@ -375,8 +375,11 @@ def label_confusion(pred, truth):
     require_device(pred, truth)
     counts = torch.zeros((5, 5), dtype=torch.int64, device=pred.device)
     if pred.numel():
-        check(_lib.load().gts_label_confusion_i16(ptr(pred), ptr(truth), ptr(counts), pred.numel(),
-                                                  current_stream()), "gts_label_confusion_i16")
+        lib = _lib.load()
+        scratch = torch.empty(lib.gts_label_confusion_workspace(pred.numel()), dtype=torch.uint8,
+                              device=pred.device)
+        check(lib.gts_label_confusion_i16(ptr(pred), ptr(truth), ptr(counts), ptr(scratch), scratch.numel(),
+                                          pred.numel(), current_stream()), "gts_label_confusion_i16")
     return counts
 
 

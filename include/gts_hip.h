@@ -176,10 +176,11 @@ int32_t gts_argmax_scatter_i16(const float* scores, const int16_t* relabel, cons
  * (calculate_dice_from_logical_array) reached from GNN.evaluate, model/gnn_model.py:76-87.
  * counts[5*cp + ct] += #{ i : class(pred[i]) == cp and class(truth[i]) == ct }, where
  * class(v) = v for 0..3 and 4 for any other value.  counts is a caller-owned int64[25] on the
- * device that the call ADDS to (zero it first); integer atomics, so the result is exact and
- * independent of scheduling. */
+ * device that the call ADDS to (zero it first); workspace is caller-owned device scratch of at
+ * least gts_label_confusion_workspace(n) bytes.  Integer sums: exact, independent of scheduling. */
+int64_t gts_label_confusion_workspace(int64_t n);
 int32_t gts_label_confusion_i16(const int16_t* pred, const int16_t* truth, int64_t* counts,
-                                int64_t n, void* stream);
+                                void* workspace, int64_t workspace_bytes, int64_t n, void* stream);
 
 /* ---- K11: dense fp32 layer GEMMs on the matrix cores -------------------------------------
  * Replace the nn.Linear calls inside DGL's SAGEConv / GATConv (fc_pool, fc_self + fc_neigh,
