@@ -66,8 +66,10 @@ __global__ __launch_bounds__(kBlock) void label_confusion_finish_kernel(
   __shared__ unsigned long long part[8][32];
   const int b = threadIdx.x & 31, slice = threadIdx.x >> 5;
   unsigned long long s = 0;
-  if (b < kBins)
+  if (b < kBins) {
+#pragma unroll 16   // independent loads, issued back to back
     for (int g = slice; g < n_groups; g += 8) s += partial[static_cast<size_t>(g) * kBins + b];
+  }
   part[slice][b] = s;
   __syncthreads();
   if (slice == 0 && b < kBins) {

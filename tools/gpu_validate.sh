@@ -21,5 +21,6 @@ GTS_OVERLAP_WGRAD=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 python tools/parse_pmc.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json | tail -12
-rm -f $OUT/prof/*/*kernel_trace.csv   # large; the stats file is what we keep
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_aux -- python tools/measure_aux_kernels.py > $OUT/aux_kernels.jsonl 2> $OUT/aux_kernels.err
+rm -f $OUT/prof/*/*kernel_trace.csv $OUT/prof_aux/*/*kernel_trace.csv   # large; the stats file is what we keep
 echo done
