@@ -191,8 +191,14 @@ constexpr int min_waves_per_simd(int wm, int wn, int tm, int tn) {
   return per_block * ((tm * tn * 16 <= 64 || per_block == 1) ? 2 : 1);
 }
 
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
-__global__ __launch_bounds__(64 * WM * WN, min_waves_per_simd(WM, WN, BM / WM / 32, BN / WN / 32))
+// DB = false: one LDS image per operand, two barriers per reduction tile; meant for two
+//   co-resident workgroups per CU that fill each other's bubbles.
+// DB = true:  two images and ONE barrier per tile: while the waves multiply tile t out of image
+//   t&1, tile t+1 (already in registers) is written to the other image and tile t+2 is requested
+//   from memory, so a workgroup that is alone on its CU (256 x 256 tiles, 16 waves: one round
+//   over the 60 000-row matrices) keeps its matrix cores fed without a partner.
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, bool DB = false>
+__global__ __launch_bounds__(64 * WM * WN, DB ? WM * WN / 4 : min_waves_per_simd(WM, WN, BM / WM / 32, BN / WN / 32))
 void gemm_kernel(const GemmArgs p) {
   constexpr int THREADS = 64 * WM * WN;
   using TA = OperandTile<BM, AKC, THREADS>;
@@ -200,11 +206,12 @@ void gemm_kernel(const GemmArgs p) {
   constexpr int WTM = BM / WM, WTN = BN / WN;    // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;    // MFMA tiles per wave
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
-  constexpr int kOperandFloats = TA::kFloats + TB::kFloats;
+  constexpr int kImage = TA::kFloats + TB::kFloats;
+  constexpr int kOperandFloats = (DB ? 2 : 1) * kImage;
   constexpr int kStageFloats = WM * WN * 32 * kKcLd;  // epilogue patches, one per wave
   __shared__ float lds[kOperandFloats > kStageFloats ? kOperandFloats : kStageFloats];
-  float* lds_a = lds;
-  float* lds_b = lds + TA::kFloats;
+  const float* lds_a = lds;
+  const float* lds_b = lds + TA::kFloats;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -274,28 +281,49 @@ void gemm_kernel(const GemmArgs p) {
   const size_t stamp_at = 4 * (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x);
   if (threadIdx.x == 0 && p.stamps) p.stamps[stamp_at] = __builtin_amdgcn_s_memrealtime();
 #endif
+  auto stash = [&](int image) {
+    TA::store(ra, lds + image * kImage);
+    TB::store(rb, lds + image * kImage + TA::kFloats);
+  };
   if (t_beg < t_end) {
     fetch_a(ra, t_beg);
     fetch_b(t_beg);
-    TA::store(ra, lds_a);
-    TB::store(rb, lds_b);
+    stash(0);
+    if (DB && t_beg + 1 < t_end) {
+      fetch_a(ra, t_beg + 1);
+      fetch_b(t_beg + 1);
+    }
     __syncthreads();
   }
 #ifdef GTS_GEMM_STAMPS
   if (threadIdx.x == 0 && p.stamps) p.stamps[stamp_at + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
-  for (int t = t_beg; t < t_end; ++t) {
-    const bool more = t + 1 < t_end;
-    if (more) {  // in flight under the MFMAs below
-      fetch_a(ra, t + 1);
-      fetch_b(t + 1);
+  if constexpr (DB) {
+    for (int t = t_beg; t < t_end; ++t) {
+      const int cur = (t - t_beg) & 1;
+      if (t + 1 < t_end) stash(cur ^ 1);  // tile t+1: requested one iteration ago
+      if (t + 2 < t_end) {                // lands under the MFMAs below
+        fetch_a(ra, t + 2);
+        fetch_b(t + 2);
+      }
+      lds_a = lds + cur * kImage;
+      lds_b = lds_a + TA::kFloats;
+      compute();
+      __syncthreads();  // image cur^1 complete for the next tile; everyone is done reading image cur
     }
-    compute();
-    __syncthreads();  // every wave is done reading this tile
-    if (more) {
-      TA::store(ra, lds_a);
-      TB::store(rb, lds_b);
-      __syncthreads();
+  } else {
+    for (int t = t_beg; t < t_end; ++t) {
+      const bool more = t + 1 < t_end;
+      if (more) {  // in flight under the MFMAs below
+        fetch_a(ra, t + 1);
+        fetch_b(t + 1);
+      }
+      compute();
+      __syncthreads();  // every wave is done reading this tile
+      if (more) {
+        stash(0);
+        __syncthreads();
+      }
     }
   }
 
@@ -490,13 +518,15 @@ unsigned long long* g_stamps = nullptr;  // diagnostic build only (tools/diag/ge
 int g_diag_flags = 0;
 #endif
 // Defaults from tools/tune_gemm.py at M = 60 000, 256-wide (profiles/r01_tune_gemm.log).
-int g_fwd_variant = 3;     // forward kernels (both operands kk-contiguous); 5 is equal in-bench but slows the K1 launch that follows
+int g_fwd_variant = -1;    // forward kernels (both operands kk-contiguous); -1 = 8 (double-buffered 256x256, one
+                           // workgroup per CU) when that fills >= 3/4 of the CUs, else 3 (64x256, two per CU);
+                           // in-bench 748-754 graphs/s with 8 vs 738 with 3 (profiles/r01_tune_gemm.log)
 int g_igrad_variant = 1;   // input-gradient kernels (B kk-strided)
 int g_wgrad_variant = -1;  // split-reduction kernel; -1 = 2 (128x256) when problems are batched, else 1
                            // (in isolation 0/1 are 5 % faster for the batch, inside the step — where it
                            // overlaps the input-gradient chain on the side stream — 2 wins by 1.3 %)
 
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, bool DB = false>
 int launch_tiles(const GemmArgs& p, int grid_y_mult, int splits, hipStream_t st) {
   GemmArgs q = p;
 #ifdef GTS_GEMM_STAMPS
@@ -505,7 +535,7 @@ int launch_tiles(const GemmArgs& p, int grid_y_mult, int splits, hipStream_t st)
 #endif
   q.tiles_n = (p.rb + BN - 1) / BN;
   dim3 grid((p.ra + BM - 1) / BM, q.tiles_n * grid_y_mult, splits);
-  gemm_kernel<BM, BN, WM, WN, AKC, BKC><<<grid, 64 * WM * WN, 0, st>>>(q);
+  gemm_kernel<BM, BN, WM, WN, AKC, BKC, DB><<<grid, 64 * WM * WN, 0, st>>>(q);
   return launch_status();
 }
 
@@ -513,12 +543,19 @@ template <bool AKC, bool BKC>
 int launch_plain(const GemmArgs& p, hipStream_t st) {
   if (p.rb <= 64) return launch_tiles<128, 64, 2, 2, AKC, BKC>(p, 1, 1, st);
   if (p.rb <= 128) return launch_tiles<128, 128, 2, 2, AKC, BKC>(p, 1, 1, st);
-  switch (BKC ? g_fwd_variant : g_igrad_variant) {
+  int variant = BKC ? g_fwd_variant : g_igrad_variant;
+  if (variant < 0) {
+    const int64_t big_tiles = static_cast<int64_t>((p.ra + 255) / 256) * ((p.rb + 255) / 256);
+    variant = big_tiles >= 192 ? 8 : 3;
+  }
+  switch (variant) {
     case 1: return launch_tiles<128, 256, 2, 4, AKC, BKC>(p, 1, 1, st);
     case 2: return launch_tiles<64, 256, 1, 4, AKC, BKC>(p, 1, 1, st);
     case 3: return launch_tiles<64, 256, 2, 4, AKC, BKC>(p, 1, 1, st);
     case 4: return launch_tiles<128, 128, 2, 2, AKC, BKC>(p, 1, 1, st);
     case 5: return launch_tiles<256, 128, 4, 2, AKC, BKC>(p, 1, 1, st);
+    case 7: return launch_tiles<256, 256, 2, 4, AKC, BKC, true>(p, 1, 1, st);
+    case 8: return launch_tiles<256, 256, 4, 4, AKC, BKC, true>(p, 1, 1, st);
     default: return launch_tiles<128, 256, 2, 2, AKC, BKC>(p, 1, 1, st);
   }
 }
@@ -534,6 +571,7 @@ inline void wgrad_tile(int64_t k, int n_problems, int* bm, int* bn) {
   *bn = k <= 64 ? 64 : 128;
   if (k > 64 && v == 2) *bn = 256;
   if (k > 64 && v == 3) *bm = 64, *bn = 256;
+  if (k > 64 && v == 4) *bm = 256, *bn = 256;
 }
 
 inline int wgrad_splits(int64_t m, int64_t n, int64_t k, int n_problems) {
@@ -541,8 +579,11 @@ inline int wgrad_splits(int64_t m, int64_t n, int64_t k, int n_problems) {
   wgrad_tile(k, n_problems, &bm, &bn);
   const int64_t tiles = (m + kBK - 1) / kBK;
   const int64_t out_tiles = ((n + bm - 1) / bm) * ((k + bn - 1) / bn) * n_problems;
-  // 2 workgroups per CU = 512 slots; never one more workgroup than slots (a lone tail round)
-  int64_t splits = out_tiles >= 512 ? 1 : 512 / out_tiles;
+  // 2 workgroups per CU = 512 slots (1 per CU for the double-buffered tiles); never one more
+  // workgroup than slots (a lone tail round)
+  const int v = wgrad_variant(n_problems);
+  const int64_t slots = (k > 64 && v == 4) ? 256 : 512;
+  int64_t splits = out_tiles >= slots ? 1 : slots / out_tiles;
   if (splits > tiles) splits = tiles;
   return static_cast<int>(splits < 1 ? 1 : splits);
 }
@@ -554,6 +595,7 @@ int launch_wgrad(const GemmArgs& p, int splits, hipStream_t st) {
     case 1: return launch_tiles<128, 128, 2, 4, false, false>(p, np, splits, st);
     case 2: return launch_tiles<128, 256, 2, 4, false, false>(p, np, splits, st);
     case 3: return launch_tiles<64, 256, 1, 4, false, false>(p, np, splits, st);
+    case 4: return launch_tiles<256, 256, 4, 4, false, false, true>(p, np, splits, st);
     default: return launch_tiles<128, 128, 2, 2, false, false>(p, np, splits, st);
   }
 }

@@ -227,7 +227,7 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
 /* ---- tuning knobs -----------------------------------------------------------------------
  * Process-wide tile selection of the K11 kernels (defaults are the tuned values; used by
  * tools/tune_gemm.py).  Returns GTS_ERR_ARGKIND for an unknown option. */
-#define GTS_OPT_GEMM_TILE 1  /* forward tile variant */
+#define GTS_OPT_GEMM_TILE 1  /* forward tile variant (-1 = automatic) */
 #define GTS_OPT_WGRAD_TILE 2 /* weight-gradient tile variant (-1 = automatic) */
 #define GTS_OPT_IGRAD_TILE 3 /* input-gradient tile variant */
 #define GTS_OPT_PROJECT_STREAMING 6  /* K12: non-temporal stores of the projected rows (default 1) */

@@ -28,7 +28,7 @@ x = torch.randn(M, F, device="cuda"); y = torch.randn(M, F, device="cuda")
 w = torch.randn(F, F, device="cuda") * 0.05; w2 = torch.randn(F, F, device="cuda") * 0.05
 b = torch.randn(F, device="cuda"); out = torch.empty(M, F, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
-for variant, bm, bn in ((3, 64, 256), (5, 256, 128), (1, 128, 256)):
+for variant, bm, bn in ((3, 64, 256), (1, 128, 256), (8, 256, 256)):
     lib.gts_set_option(1, variant)
     n_blocks = ((M + bm - 1) // bm) * ((F + bn - 1) // bn)
     stamps = torch.zeros(4 * n_blocks, dtype=torch.int64, device="cuda")
@@ -53,7 +53,7 @@ for variant, bm, bn in ((3, 64, 256), (5, 256, 128), (1, 128, 256)):
 
 # A operand cache-hot (row stride 0 in the diagnostic build): is the main loop waiting on A from HBM?
 lib.gts_diag_set_stamps(None)
-for variant in (3, 1):
+for variant in (1, 8):
     lib.gts_set_option(1, variant)
     for flags in (0, 1):
         lib.gts_diag_set_flags(flags)

@@ -39,18 +39,37 @@ def timeit(fn, flops, reps=30):
 
 
 g1 = 2.0 * M * F * F
-for v in (0, 1, 2, 3, 4, 5, 3, 5, 1):
+VARIANTS = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3, 4, 5, 7, 8, 3, 1, 8]
+
+
+def check(v):
+    """Both GEMM kinds of variant v against torch (fp32 library GEMM): max error relative to the scale."""
+    lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), P(b), P(out), M, F, F, F, 1, st)
+    want = torch.relu(x @ w.t() + y @ w2.t() + b)
+    e1 = float((out - want).abs().max() / want.abs().max())
+    lib.gts_linear_bwd_input_f32(P(x), P(w), P(y), P(w2), P(x), P(out), M, F, F, F, st)
+    want = (x @ w + y @ w2) * (x > 0)
+    e2 = float((out - want).abs().max() / want.abs().max())
+    assert e1 < 1e-5 and e2 < 1e-5, (v, e1, e2)
+    return max(e1, e2)
+
+
+for v in VARIANTS:
     lib.gts_set_option(1, v)
     lib.gts_set_option(3, v)
+    err = check(v)
     r = [timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), None, None, P(b), P(out), M, F, F, 0, 1, st), g1),
          timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), P(b), P(out), M, F, F, F, 1, st), 2 * g1),
          timeit(lambda: lib.gts_linear_bwd_input_f32(P(x), P(w), None, None, None, P(out), M, F, F, 0, st), g1),
          timeit(lambda: lib.gts_linear_bwd_input_f32(P(x), P(w), P(y), P(w2), P(x), P(out), M, F, F, F, st), 2 * g1)]
-    print(f"fwd/igrad variant {v}: " + " | ".join(f"{us:7.1f} us {tf:6.1f} TF" for us, tf in r), flush=True)
-lib.gts_set_option(1, 3)
+    print(f"fwd/igrad variant {v}: " + " | ".join(f"{us:7.1f} us {tf:6.1f} TF" for us, tf in r)
+          + f" | max rel err {err:.1e}", flush=True)
+lib.gts_set_option(1, -1)
 lib.gts_set_option(3, 1)
+if len(sys.argv) > 2 and sys.argv[2] == "nowgrad":
+    sys.exit(0)
 arr1, arr3 = ctypes.c_void_p * 1, ctypes.c_void_p * 3
-for v in range(4):
+for v in (0, 1, 2, 3, 4, 2, 4):
     lib.gts_set_option(2, v)
     r = [timeit(lambda: lib.gts_linear_bwd_weight_f32(arr1(P(x)), arr1(P(y)), arr1(P(gw[0])), arr1(P(gb[0])), 1,
                                                       P(ws), ws.numel() * 4, M, F, F, st), g1),
