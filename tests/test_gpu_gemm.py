@@ -51,6 +51,23 @@ def test_linear_forward(m, k, n, dual, relu, bias):
     _check(got, want, bound)
 
 
+@pytest.mark.parametrize("m,k,n,dual", [(49999, 132, 260, True), (60000, 256, 256, False)])
+def test_linear_forward_one_round_tile(m, k, n, dual):
+    """Shapes that select the double-buffered 256x256 tile (>= 192 of them): ragged rows and
+    columns, both reduction segments, bias + ReLU."""
+    a0, w0 = _rand(m, k, seed=11), _rand(n, k, seed=12)
+    a1, w1 = (_rand(m, k + 4, seed=13), _rand(n, k + 4, seed=14)) if dual else (None, None)
+    b = _rand(n, seed=15)
+    want = a0.double() @ w0.double().t() + b.double()
+    bound = a0.double().abs() @ w0.double().abs().t() + b.double().abs()
+    if dual:
+        want += a1.double() @ w1.double().t()
+        bound += a1.double().abs() @ w1.double().abs().t()
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    got = dense.linear_fwd(dev(a0), dev(w0), dev(a1), dev(w1), bias=dev(b), relu=True)
+    _check(got, want.clamp(min=0), bound)
+
+
 @pytest.mark.parametrize("m,k,n", SHAPES)
 @pytest.mark.parametrize("dual", [False, True])
 def test_linear_input_gradient(m, k, n, dual):
