@@ -262,13 +262,15 @@ def main():
         ms = timer.mean_ms()
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms else None
         traffic = None
+        # the committed PMC / rocprof figures were taken on the default workload only
+        profiled = args.graphs_per_gpu == 4 and args.graph_kind == "lattice"
         pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
+        if profiled and os.path.exists(pmc_path):
             with open(pmc_path) as fh:
                 traffic = json.load(fh).get(cfg["kernel"] + "_bytes_per_launch")
         rocprof_us = None     # kernel-only duration from the committed rocprofv3 summary, for comparison:
         avg_path = os.path.join(REPO, "profiles", "rocprof_kernel_avg.json")   # event brackets add the
-        if os.path.exists(avg_path):                                             # two kernel boundaries
+        if profiled and os.path.exists(avg_path):                                # two kernel boundaries
             with open(avg_path) as fh:
                 rocprof_us = json.load(fh).get(cfg["kernel"] + "_avg_us")
         workloads = {
