@@ -10,12 +10,13 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgts_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "gts_hip.h")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
 _i64 = ctypes.c_int64
 _f32 = ctypes.c_float
+_f64 = ctypes.c_double
 
 # name -> argtypes (restype is int32 unless noted)
 SIGNATURES = {
@@ -36,6 +37,7 @@ SIGNATURES = {
     "gts_project_argmax_occupancy_i16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "gts_crop_concat_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p],
     "gts_argmax_scatter_i16": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p],
+    "gts_adamw_f32": [_p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _i64, _p],
     "gts_label_confusion_workspace": [_i64],
     "gts_label_confusion_i16": [_p, _p, _p, _p, _i64, _i64, _p],
     "gts_linear_fwd_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p],

@@ -81,6 +81,13 @@ class FlatGradSync:
         self.flat = None
         self._scalars = None
 
+    def flat_gradients(self):
+        """The normalised gradients of the last step as one contiguous fp32 tensor (parameter
+        order), for optimizers that consume a flat buffer (gts.optim.FlatAdamW)."""
+        if self.flat is None:
+            raise RuntimeError("call all_reduce_and_normalise() first")
+        return self.flat[:self.n_grad]
+
     def zero_grad(self):
         """Replaces optimizer.zero_grad(): drops the gradients (nothing is launched)."""
         for p in self.params:

@@ -8,6 +8,8 @@ scripts/train_gnn.py drives it unchanged.
 
 Differences that do not change results:
   * the device must be an AMD GPU — there is no CPU path (the HIP library is the product);
+  * AdamW (:28) runs as one HIP launch over a flat parameter buffer (`gts.optim.FlatAdamW`, a
+    `torch.optim.Optimizer` with the same update rule and a single param group);
   * `ExponentialLR(..., verbose=False)` (reference :29) raises on current PyTorch; the kwarg
     is dropped, behaviour is the same;
   * the per-step `loss.item()` host sync (:43) becomes one read-back per epoch (same values);
@@ -23,6 +25,7 @@ from data_processing.data_loader import ImageGraphDataset, minibatch_graphs
 from data_processing.graph_io import project_nodes_to_img
 from gts import dist as gdist
 from gts import ops as gops
+from gts.optim import FlatAdamW
 
 from . import evaluation
 from .networks import init_graph_net
@@ -61,10 +64,10 @@ class GNN:
         self.class_weights = class_weights
         self.net = init_graph_net(model_type, hyperparameters)
         self.net.to(self.device)
-        # same AdamW as the reference (:28); fused=True only selects torch's single-kernel
-        # implementation of the identical update
-        self.optimizer = torch.optim.AdamW(self.net.parameters(), lr=hyperparameters.lr,
-                                           weight_decay=hyperparameters.w_decay, fused=True)
+        # same AdamW update as the reference's torch.optim.AdamW (:28), as one HIP pass over a
+        # flat parameter buffer (gts_adamw_f32); a torch Optimizer, so the scheduler below drives it
+        self.optimizer = FlatAdamW(self.net.parameters(), lr=hyperparameters.lr,
+                                   weight_decay=hyperparameters.w_decay)
         self.lr_decay = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, hyperparameters.lr_decay,
                                                                last_epoch=-1)
         # same function as torch.nn.CrossEntropyLoss(weight=class_weights) (reference :30), as one
@@ -94,7 +97,10 @@ class GNN:
         self.grad_sync.zero_grad()
         self.grad_sync.weighted_ce_backward(logits, labels, self.class_weights)
         loss = self.grad_sync.all_reduce_and_normalise()
-        self.optimizer.step()
+        if isinstance(self.optimizer, FlatAdamW):
+            self.optimizer.step(flat_grad=self.grad_sync.flat_gradients())
+        else:
+            self.optimizer.step()
         return loss.clone()
 
     def _to_device(self, graph, features, labels=None):

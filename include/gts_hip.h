@@ -170,6 +170,15 @@ int32_t gts_argmax_scatter_i16(const float* scores, const int16_t* relabel, cons
                                int64_t cy, int64_t cz, int64_t dim_y, int64_t dim_z,
                                int64_t n_classes, void* stream);
 
+/* ---- K14: AdamW step over one flat fp32 buffer ---------------------------------------------
+ * torch.optim.AdamW(net.parameters(), lr, weight_decay).step() (model/gnn_model.py:28,46), same
+ * update rule (decoupled decay, bias-corrected moments, no amsgrad), for parameters, gradients
+ * and both moment buffers laid out as ONE contiguous fp32 range each.  `step` is the 1-based
+ * count of this update (for the bias corrections).  In-place on param / exp_avg / exp_avg_sq. */
+int32_t gts_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      double lr, double beta1, double beta2, double eps, double weight_decay,
+                      int64_t step, void* stream);
+
 /* ---- K15: label coincidence counts for the Dice metrics -------------------------------------
  * Replaces the numpy mask arithmetic of model/evaluation.py:24-46 (count_node_labels,
  * calculate_node_dices), :64-79 (voxel Dice in calculate_brats_metrics) and :98-106

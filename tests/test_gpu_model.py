@@ -13,6 +13,7 @@ import torch.nn.functional as F
 import gts
 from gts import nn as gnn
 from gts import synth
+from gts.optim import FlatAdamW
 from model.networks import init_graph_net
 from oracle import graph_ref, torch_ref
 from tests.helpers import copy_state, random_coo, ref_and_gts
@@ -238,12 +239,55 @@ def test_gnn_harness_trains_and_checkpoints(tmp_path):
     feats, labels = torch.FloatTensor(item[2]), torch.LongTensor(item[3])
     opt = torch_ref.make_optimizer(ref, lr=hp.lr, w_decay=hp.w_decay)
     loss_ref = torch_ref.train_step(ref, tg, feats, labels, torch.tensor(hp.class_weights), opt)
-    model.optimizer = torch.optim.AdamW(model.net.parameters(), lr=hp.lr, weight_decay=hp.w_decay)
+    model.optimizer = FlatAdamW(model.net.parameters(), lr=hp.lr, weight_decay=hp.w_decay)
     model.net.train()
     loss = model.train_step(item[1].to(model.device), feats.to(model.device), labels.to(model.device))
     assert abs(float(loss) - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
     for (k, a), (_, b) in zip(model.net.state_dict().items(), ref.state_dict().items()):
         assert torch.allclose(a.cpu(), b, rtol=1e-4, atol=1e-6), k
+
+
+def test_flat_adamw_matches_torch_adamw_over_several_steps():
+    """gts_adamw_f32 over the flat buffer against torch.optim.AdamW (the reference's optimizer,
+    model/gnn_model.py:28) on a CPU twin: 25 steps with a decaying learning rate, odd tensor sizes;
+    parameters stay views of the flat buffer and load_state_dict keeps working."""
+    torch.manual_seed(3)
+    shapes = [(7, 5), (5,), (33, 9), (1,), (256, 4), (4,)]
+    cpu = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    gpu = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in cpu]
+    ref = torch.optim.AdamW(cpu, lr=3e-3, weight_decay=1e-2)
+    mine = FlatAdamW(gpu, lr=3e-3, weight_decay=1e-2)
+    sched_ref = torch.optim.lr_scheduler.ExponentialLR(ref, 0.9)
+    sched = torch.optim.lr_scheduler.ExponentialLR(mine, 0.9)
+    for step in range(25):
+        grads = [torch.randn(s) * (1.0 + step) for s in shapes]
+        for p, q, g in zip(cpu, gpu, grads):
+            p.grad, q.grad = g.clone(), g.to(DEV)
+        ref.step()
+        mine.step()
+        if step % 5 == 4:
+            sched_ref.step()
+            sched.step()
+        mine.zero_grad()
+        assert all(q.grad is None for q in gpu)
+    assert mine.param_groups[0]["lr"] == ref.param_groups[0]["lr"]
+    off = 0
+    for p, q in zip(cpu, gpu):
+        assert torch.allclose(q.detach().cpu(), p.detach(), rtol=2e-5, atol=1e-6)
+        assert q.data_ptr() == mine.flat_param.data_ptr() + 4 * off
+        off += q.numel()
+    flat = torch.cat([torch.randn(s).reshape(-1) for s in shapes]).to(DEV)
+    before = mine.flat_param.clone()
+    mine.step(flat_grad=flat)                       # the data-parallel entry: gradients already flat
+    assert not torch.equal(before, mine.flat_param)
+    gpu[0].grad = None
+    with pytest.raises(gts.GtsError):
+        mine.step()
+    with pytest.raises(gts.GtsError):
+        mine.step(flat_grad=flat[:-1])
+    gpu[2].data = gpu[2].data.clone()               # re-allocated parameter: refuse instead of updating a stale buffer
+    with pytest.raises(gts.GtsError):
+        mine.step(flat_grad=flat)
 
 
 def test_rccl_world_size_one_flat_gradient_path():
