@@ -522,9 +522,8 @@ int g_fwd_variant = -1;    // forward kernels (both operands kk-contiguous); -1 
                            // workgroup per CU) when that fills >= 3/4 of the CUs, else 3 (64x256, two per CU);
                            // in-bench 748-754 graphs/s with 8 vs 738 with 3 (profiles/r01_tune_gemm.log)
 int g_igrad_variant = 1;   // input-gradient kernels (B kk-strided)
-int g_wgrad_variant = -1;  // split-reduction kernel; -1 = 2 (128x256) when problems are batched, else 1
-                           // (in isolation 0/1 are 5 % faster for the batch, inside the step — where it
-                           // overlaps the input-gradient chain on the side stream — 2 wins by 1.3 %)
+int g_wgrad_variant = -1;  // split-reduction kernel; -1 = 1 (128x128 tiles, 8 waves): fastest for one problem and,
+                           // on a single stream, for the batch of three (789 graphs/s vs 777 with 2 = 128x256)
 
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, bool DB = false>
 int launch_tiles(const GemmArgs& p, int grid_y_mult, int splits, hipStream_t st) {
@@ -562,7 +561,8 @@ int launch_plain(const GemmArgs& p, hipStream_t st) {
 
 // tile edge lengths of the split-reduction variants (needed to size the workspace)
 inline int wgrad_variant(int n_problems) {
-  return g_wgrad_variant >= 0 ? g_wgrad_variant : (n_problems > 1 ? 2 : 1);
+  (void)n_problems;
+  return g_wgrad_variant >= 0 ? g_wgrad_variant : 1;
 }
 
 inline void wgrad_tile(int64_t k, int n_problems, int* bm, int* bn) {

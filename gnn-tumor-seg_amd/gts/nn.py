@@ -54,9 +54,11 @@ class _SagePoolLayer(torch.autograd.Function):
         return None, gh, g_wp, g_bp, g_ws, g_wn, g_bias, None, None
 
 
-# Run the weight gradients of the fused stack on a second stream (see _SagePoolStack.backward).
-# GTS_OVERLAP_WGRAD=0 in the environment keeps everything on one stream.
-OVERLAP_WEIGHT_GRADS = os.environ.get("GTS_OVERLAP_WGRAD", "1") != "0"
+# GTS_OVERLAP_WGRAD=1 runs the weight gradients of the fused stack on a second, low-priority stream
+# (see _SagePoolStack.backward).  Off by default: with the current kernels the side stream takes
+# CUs from the input-gradient chain it was meant to fill in behind (757 graphs/s with it, 777-789
+# without, profiles/r01_tune_gemm.log).
+OVERLAP_WEIGHT_GRADS = os.environ.get("GTS_OVERLAP_WGRAD", "0") != "0"
 _side_streams = {}
 
 
