@@ -36,6 +36,9 @@ for _p in (REPO, PKG):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+# dmabuf IPC for RCCL / device-tensor sharing: must be in the environment before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
