@@ -68,13 +68,13 @@ def test_linear_forward_one_round_tile(m, k, n, dual):
     _check(got, want.clamp(min=0), bound)
 
 
-def test_forward_tile_variants_are_bitwise_identical_at_full_size(hip_lib):
-    """Every tile variant walks the reduction in the same order, so the C2-sized forward GEMM of
-    the one-round 256x256 tile (default there) equals the 64x256 tile the small-graph parity
-    tests exercise, bit for bit."""
-    m, f = 60000, 256
-    a0, a1 = _rand(m, f, seed=21).to(DEV), _rand(m, f, seed=22).to(DEV)
-    w0, w1, b = _rand(f, f, seed=23).to(DEV), _rand(f, f, seed=24).to(DEV), _rand(f, seed=25).to(DEV)
+@pytest.mark.parametrize("m,f,dual", [(60000, 256, True), (49999, 1024, False)])
+def test_forward_tile_variants_are_bitwise_identical_at_full_size(hip_lib, m, f, dual):
+    """Every tile variant walks the reduction in the same order, so the C2- / C3-sized forward
+    GEMM of the one-round 256x256 tile (default there) equals the 64x256 tile the small-graph
+    parity tests exercise, bit for bit."""
+    a0, w0, b = _rand(m, f, seed=21).to(DEV), _rand(f, f, seed=23).to(DEV), _rand(f, seed=25).to(DEV)
+    a1, w1 = (_rand(m, f, seed=22).to(DEV), _rand(f, f, seed=24).to(DEV)) if dual else (None, None)
     outs = []
     try:
         for variant in (-1, 8, 3, 1):
