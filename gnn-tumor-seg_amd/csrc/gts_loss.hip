@@ -37,9 +37,14 @@ __global__ __launch_bounds__(kBlock) void weighted_ce_kernel(
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < n_classes; ++c) v[c] = expf(v[c] - mx), sum += v[c];
-    const int y = static_cast<int>(labels[i]);
-    const float w = class_w != nullptr ? class_w[y] : 1.0f;
-    num += w * (logf(sum) + mx - x[y]);
+    // a label outside [0, C): torch's ignore_index (-100) contributes nothing; anything else is an
+    // error that torch reports with a device assert — here it poisons the loss with NaN instead of
+    // reading class_w / the logits row out of bounds
+    const long long label = labels[i];
+    const bool valid = label >= 0 && label < n_classes;
+    const int y = valid ? static_cast<int>(label) : 0;
+    const float w = !valid ? 0.0f : (class_w != nullptr ? class_w[y] : 1.0f);
+    num += valid ? w * (logf(sum) + mx - x[y]) : (label == -100 ? 0.0f : NAN);
     den += w;
     if (grad_unscaled != nullptr) {
       float* g = grad_unscaled + i * n_classes;

@@ -43,6 +43,17 @@ def _pad4_rows(t):
     return t.contiguous() if pad == 0 else F.pad(t, (0, 0, 0, pad)).contiguous()
 
 
+def _mat(t, name):
+    if t.dim() != 2:
+        raise _lib.GtsError(f"{name} must be a matrix, got shape {tuple(t.shape)}")
+    return t
+
+
+def _same(a, b, what):
+    if a != b:
+        raise _lib.GtsError(f"shapes do not match: {what} ({a} vs {b})")
+
+
 def _chk(*tensors):
     for t in tensors:
         if t is not None and t.dtype != torch.float32:
@@ -52,6 +63,15 @@ def _chk(*tensors):
 
 def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False):
     """out = act(a0 @ w0^T [+ a1 @ w1^T] + bias).  a [M,K], w [N,K] (torch Linear layout)."""
+    _same(_mat(a0, "a0").shape[1], _mat(w0, "w0").shape[1], "inner dims of a0 @ w0^T")
+    if (a1 is None) != (w1 is None):
+        raise _lib.GtsError("a1 and w1 go together")
+    if a1 is not None:
+        _same(_mat(a1, "a1").shape[1], _mat(w1, "w1").shape[1], "inner dims of a1 @ w1^T")
+        _same(a1.shape[0], a0.shape[0], "rows of a0 / a1")
+        _same(w1.shape[0], w0.shape[0], "rows of w0 / w1")
+    if bias is not None:
+        _same(tuple(bias.shape), (w0.shape[0],), "bias vs output columns")
     a0, w0 = _pad4_cols(a0), _pad4_cols(w0)
     if a1 is not None:
         a1, w1 = _pad4_cols(a1), _pad4_cols(w1)
@@ -76,6 +96,15 @@ def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False):
 
 def linear_bwd_input(g0, w0, g1=None, w1=None, relu_mask=None):
     """g0 @ w0 [+ g1 @ w1].  g [M,N], w [N,K] -> [M,K]; zeroed where relu_mask [M,K] <= 0."""
+    _same(_mat(g0, "g0").shape[1], _mat(w0, "w0").shape[0], "inner dims of g0 @ w0")
+    if (g1 is None) != (w1 is None):
+        raise _lib.GtsError("g1 and w1 go together")
+    if g1 is not None:
+        _same(_mat(g1, "g1").shape[1], _mat(w1, "w1").shape[0], "inner dims of g1 @ w1")
+        _same(g1.shape[0], g0.shape[0], "rows of g0 / g1")
+        _same(w1.shape[1], w0.shape[1], "columns of w0 / w1")
+    if relu_mask is not None:
+        _same(tuple(relu_mask.shape), (g0.shape[0], w0.shape[1]), "relu_mask vs result")
     k = w0.shape[1]
     kp = k + (-k) % 4
     g0, w0 = _pad4_cols(g0), _pad4_cols(_pad4_rows(w0))

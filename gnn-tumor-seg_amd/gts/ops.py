@@ -20,6 +20,12 @@ def _timed(name, launch):
     return timer(launch) if timer is not None else launch()
 
 
+def _expect(tensor, shape, name):
+    """Operand shapes are checked on the host: the kernels index by the sizes they are given."""
+    if tensor is not None and tuple(tensor.shape) != tuple(shape):
+        raise _lib.GtsError(f"{name}: expected shape {tuple(shape)}, got {tuple(tensor.shape)}")
+
+
 def _f32(*tensors):
     for t in tensors:
         if t is not None and t.dtype != torch.float32:
@@ -33,9 +39,9 @@ def spmm_max_fwd(g, x, want_arg=True):
     _f32(x)
     require_device(x)
     d = g.dev()
+    if x.dim() != 2 or x.shape[0] != g.n:
+        raise _lib.GtsError(f"features must be [graph nodes = {g.n}, F], got {tuple(x.shape)}")
     n, f = g.n, x.shape[1]
-    if x.shape[0] != n:
-        raise _lib.GtsError(f"feature rows {x.shape[0]} != graph nodes {n}")
     out = torch.empty((n, f), dtype=torch.float32, device=x.device)
     ab = g.arg_bytes if want_arg else 0
     arg = torch.empty((n, f), dtype=_ARG_DTYPE[ab], device=x.device) if want_arg else None
@@ -56,7 +62,13 @@ def spmm_max_bwd(g, gout, arg, relu_src=None):
     _f32(gout, relu_src)
     require_device(gout, arg, relu_src)
     d = g.dev()
+    if gout.dim() != 2 or gout.shape[0] != g.n:
+        raise _lib.GtsError(f"gradient must be [graph nodes = {g.n}, F], got {tuple(gout.shape)}")
     n, f = g.n, gout.shape[1]
+    _expect(arg, (n, f), "arg")
+    _expect(relu_src, (n, f), "relu_src")
+    if arg.dtype != _ARG_DTYPE[g.arg_bytes]:
+        raise _lib.GtsError(f"arg dtype {arg.dtype} does not belong to this graph ({_ARG_DTYPE[g.arg_bytes]})")
     gx = torch.empty((n, f), dtype=torch.float32, device=gout.device)
     check(_lib.load().gts_spmm_max_bwd_f32(ptr(d.t_indptr), ptr(d.t_indices), ptr(d.t_slot), ptr(gout),
                                            ptr(arg), arg.element_size(), ptr(relu_src), ptr(gx), n, f,
@@ -72,11 +84,11 @@ def spmm_sum_raw(g, x, transposed=False, div_in=None, div_out=None, add_self=Fal
     d = g.dev()
     indptr, indices = (d.t_indptr, d.t_indices) if transposed else (d.indptr, d.indices)
     n = g.n
-    if x.shape[0] != n:
-        raise _lib.GtsError(f"feature rows {x.shape[0]} != graph nodes {n}")
-    if x.dim() != 2:
-        raise _lib.GtsError("spmm_sum expects a 2-D feature matrix")
+    if x.dim() != 2 or x.shape[0] != n:
+        raise _lib.GtsError(f"features must be [graph nodes = {n}, F], got {tuple(x.shape)}")
     f = x.shape[1]
+    _expect(div_in, (n,), "div_in")
+    _expect(div_out, (n,), "div_out")
     out = torch.empty_like(x)
     check(_lib.load().gts_spmm_sum_f32(ptr(indptr), ptr(indices), ptr(x), ptr(out), ptr(div_in), ptr(div_out),
                                        1 if add_self else 0, n, f, current_stream()), "gts_spmm_sum_f32")
@@ -137,7 +149,14 @@ def spmm_reduce(g, x, mode):
 # ---------------------------------------------------------------- autograd: GAT
 def _gat_fwd(g, ft, el, er, slope, bias=None, residual=None, activation=0):
     d = g.dev()
+    if ft.dim() != 3 or ft.shape[0] != g.n:
+        raise _lib.GtsError(f"ft must be [graph nodes = {g.n}, H, D], got {tuple(ft.shape)}")
     n, h, dim = ft.shape
+    _expect(el, (n, h), "el")
+    _expect(er, (n, h), "er")
+    _expect(bias, (h * dim,), "bias")
+    if residual is not None and (residual.shape[0] != n or residual.numel() != n * h * dim):
+        raise _lib.GtsError(f"residual must hold [{n}, {h}*{dim}] values, got {tuple(residual.shape)}")
     out = torch.empty_like(ft)
     attn = torch.empty((g.number_of_edges(), h), dtype=torch.float32, device=ft.device)
     lib = _lib.load()
@@ -150,7 +169,15 @@ def _gat_fwd(g, ft, el, er, slope, bias=None, residual=None, activation=0):
 def _gat_bwd(g, ft, el, er, attn, gout, slope, attn_l=None, attn_r=None):
     """(gft, gel, ger); with attn_l/attn_r the score-dot-product gradient is folded into gft."""
     d = g.dev()
+    if ft.dim() != 3 or ft.shape[0] != g.n:
+        raise _lib.GtsError(f"ft must be [graph nodes = {g.n}, H, D], got {tuple(ft.shape)}")
     n, h, dim = ft.shape
+    _expect(el, (n, h), "el")
+    _expect(er, (n, h), "er")
+    _expect(attn, (g.number_of_edges(), h), "attn")
+    _expect(gout, (n, h, dim), "gout")
+    _expect(attn_l, (h, dim), "attn_l")
+    _expect(attn_r, (h, dim), "attn_r")
     lib = _lib.load()
     ge = torch.empty_like(attn)
     ger = torch.empty_like(er)
@@ -194,7 +221,12 @@ def gat_scores(ft, attn_l, attn_r):
     ft, attn_l, attn_r = ft.contiguous(), attn_l.contiguous(), attn_r.contiguous()
     _f32(ft, attn_l, attn_r)
     require_device(ft, attn_l, attn_r)
+    if ft.dim() != 3:
+        raise _lib.GtsError(f"ft must be [N, H, D], got {tuple(ft.shape)}")
     n, h, dim = ft.shape
+    attn_l, attn_r = attn_l.reshape(-1, dim), attn_r.reshape(-1, dim)
+    _expect(attn_l, (h, dim), "attn_l")
+    _expect(attn_r, (h, dim), "attn_r")
     el = torch.empty((n, h), dtype=torch.float32, device=ft.device)
     er = torch.empty_like(el)
     check(_lib.load().gts_gat_scores_f32(ptr(ft), ptr(attn_l), ptr(attn_r), ptr(el), ptr(er), n, h, dim,
@@ -211,6 +243,8 @@ def gat_act_bwd(gout, out, activation, want_bias_grad):
     """(g_pre, g_bias): g_pre = gout * act'(out) (ELU via its output), g_bias = g_pre.sum(0)."""
     gout = gout.contiguous()
     n, cols = gout.shape[0], gout[0].numel()
+    if activation:
+        _expect(out, gout.shape, "out")
     g_pre = torch.empty_like(gout) if activation else gout
     g_bias = torch.empty(cols, dtype=torch.float32, device=gout.device) if want_bias_grad else None
     ws = _reduce_ws(n, cols, gout.device) if want_bias_grad else None
@@ -223,6 +257,8 @@ def gat_act_bwd(gout, out, activation, want_bias_grad):
 def gat_param_grad(ft, gel, ger):
     """(g_attn_l, g_attn_r) [H,D] = sum_n gel[n,h] ft[n,h,:], sum_n ger[n,h] ft[n,h,:]."""
     n, h, dim = ft.shape
+    _expect(gel, (n, h), "gel")
+    _expect(ger, (n, h), "ger")
     gl = torch.empty((h, dim), dtype=torch.float32, device=ft.device)
     gr = torch.empty_like(gl)
     ws = _reduce_ws(n, h * dim, ft.device)
@@ -392,9 +428,10 @@ class _WeightedCE(torch.autograd.Function):
         logits, labels = logits.contiguous(), labels.contiguous()
         _f32(logits, class_w)
         require_device(logits, labels, class_w)
-        if labels.dtype != torch.int64 or labels.shape != logits.shape[:1]:
-            raise _lib.GtsError("labels must be int64 [N]")
+        if logits.dim() != 2 or labels.dtype != torch.int64 or labels.shape != logits.shape[:1]:
+            raise _lib.GtsError("weighted CE takes logits [N, C] and int64 labels [N]")
         n, c = logits.shape
+        _expect(class_w, (c,), "class_w")
         lib = _lib.load()
         ws = torch.empty(max(1, lib.gts_weighted_ce_workspace(n) // 4), dtype=torch.float32, device=logits.device)
         grad = torch.empty_like(logits) if ctx.needs_input_grad[0] else None

@@ -428,3 +428,81 @@ def test_gat_layer_with_odd_head_width_uses_the_op_by_op_path():
     yd.backward(gout.to(DEV))
     _close(yd, ref(tg, x), 1e-4, 1e-5)
     _close(xd.grad, xr.grad, 1e-3, 1e-5)
+
+
+def test_shape_mismatches_raise_on_the_host_before_any_launch():
+    """The kernels index by the sizes they are handed, so every wrapper checks operand shapes
+    first (a mismatch must be a Python error, never a wrong result or a GPU fault)."""
+    from gts import dense, ops
+
+    src, dst = random_coo(50, 300, seed=2)
+    g = gts.Graph(src, dst, 50).to(DEV)
+    x = torch.randn(50, 8, device=DEV)
+    with pytest.raises(gts.GtsError):
+        ops.spmm_max_fwd(g, x[:49])
+    out, arg = ops.spmm_max_fwd(g, x)
+    with pytest.raises(gts.GtsError):
+        ops.spmm_max_bwd(g, out, arg[:, :4])
+    with pytest.raises(gts.GtsError):
+        ops.spmm_max_bwd(g, out, arg, relu_src=x[:, :4])
+    with pytest.raises(gts.GtsError):
+        ops.spmm_sum_raw(g, x, div_out=torch.ones(49, device=DEV))
+    ft, el = torch.randn(50, 2, 4, device=DEV), torch.randn(50, 2, device=DEV)
+    with pytest.raises(gts.GtsError):
+        ops._gat_fwd(g, ft, el[:, :1], el, 0.2)
+    with pytest.raises(gts.GtsError):
+        ops._gat_fwd(g, ft, el, el, 0.2, bias=torch.zeros(7, device=DEV))
+    with pytest.raises(gts.GtsError):
+        ops._gat_fwd(g, ft, el, el, 0.2, residual=torch.zeros(50, 7, device=DEV))
+    with pytest.raises(gts.GtsError):
+        ops.gat_scores(ft, torch.zeros(3, 4, device=DEV), torch.zeros(2, 4, device=DEV))
+    a, w = torch.randn(50, 8, device=DEV), torch.randn(16, 12, device=DEV)
+    with pytest.raises(gts.GtsError):
+        dense.linear_fwd(a, w)
+    with pytest.raises(gts.GtsError):
+        dense.linear_fwd(a, w[:, :8], bias=torch.zeros(15, device=DEV))
+    with pytest.raises(gts.GtsError):
+        dense.linear_fwd(a, w[:, :8], a[:49], w[:, :8])
+    with pytest.raises(gts.GtsError):
+        dense.linear_bwd_input(a, w)                        # g [50,8] @ w [16,12]
+    with pytest.raises(gts.GtsError):
+        dense.linear_bwd_input(a, w[:8], relu_mask=torch.ones(50, 11, device=DEV))
+    with pytest.raises(gts.GtsError):
+        dense.linear_bwd_weight_multi([(a, a, False), (a[:49], a[:49], False)])
+    with pytest.raises(gts.GtsError):
+        ops.weighted_cross_entropy(a, torch.zeros(50, dtype=torch.int64, device=DEV), torch.ones(7, device=DEV))
+
+
+def test_cross_entropy_labels_outside_the_classes():
+    """ignore_index (-100) rows contribute nothing, as in torch; any other out-of-range label
+    gives a NaN loss (torch: device assert) and never an out-of-bounds read."""
+    from gts import ops
+
+    logits = torch.randn(40, 4, device=DEV, requires_grad=True)
+    labels = torch.randint(0, 4, (40,), device=DEV)
+    labels[::7] = -100
+    w = torch.tensor([0.1, 1.0, 2.0, 2.0], device=DEV)
+    got = ops.weighted_cross_entropy(logits, labels, w)
+    want = F.cross_entropy(logits.detach().cpu(), labels.cpu(), weight=w.cpu())
+    assert abs(float(got) - float(want)) < 1e-5
+    got.backward()
+    assert not logits.grad[::7].any()
+    labels[3] = 4
+    assert torch.isnan(ops.weighted_cross_entropy(logits.detach(), labels, w))
+    labels[3] = 2 ** 40
+    assert torch.isnan(ops.weighted_cross_entropy(logits.detach(), labels, w))
+
+
+def test_reference_hardcoded_gat_defaults_are_inconsistent_and_fail_loudly():
+    """utils/hyperparam_helpers.py:39-41 pairs 4 layer sizes with heads [4,4,3,3,4,4]: the output
+    layer is built for 256*4 inputs but receives 256*3 (model/networks.py:52-56), so the reference
+    fails in the last layer's matmul.  Same model here, same failure — as a shape error."""
+    from model.networks import init_graph_net
+    from utils.hyperparam_helpers import populate_hardcoded_hyperparameters
+
+    net = init_graph_net("GAT", populate_hardcoded_hyperparameters("GAT")).to(DEV)
+    assert [layer.fc.weight.shape[1] for layer in net.layers] == [20, 1024, 1024, 768, 1024]
+    src, dst = random_coo(60, 400, seed=3)
+    g = gts.Graph(np.concatenate([src, np.arange(60)]), np.concatenate([dst, np.arange(60)]), 60).to(DEV)
+    with pytest.raises(gts.GtsError, match="shapes do not match"):
+        net(g, torch.randn(60, 20, device=DEV))
