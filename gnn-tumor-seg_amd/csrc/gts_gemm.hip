@@ -34,7 +34,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kBK = 32;         // reduction elements per LDS tile
 constexpr int kKcLd = kBK + 4;  // padded row of a kk-contiguous LDS image
-constexpr int kMaxProblems = 4;
+constexpr int kMaxProblems = 32;
 
 struct GemmArgs {
   const float* a[2];    // forward / input grad: the two (a, b) reduction segments
@@ -59,6 +59,17 @@ struct GemmArgs {
   unsigned long long* stamps;  // diagnostic build only: 4 x s_memrealtime per workgroup
 #endif
 };
+
+// Entry `index` of an array member of the kernel's (single, by-value) argument struct, read
+// straight from the kernarg segment with a scalar load.  Indexing the by-value copy with a
+// runtime value would make the compiler move the whole struct to scratch memory.
+template <typename T>
+__device__ __forceinline__ T kernarg_entry(size_t member_offset, int index) {
+  typedef const __attribute__((address_space(4))) char* KernargBytes;
+  typedef const __attribute__((address_space(4))) T* KernargT;
+  KernargBytes base = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr();
+  return *(KernargT)(base + member_offset + sizeof(T) * index);
+}
 
 template <int ROWS, bool KC, int THREADS>
 struct OperandTile {
@@ -218,13 +229,11 @@ void gemm_kernel(const GemmArgs p) {
   const int problem = p.n_problems ? blockIdx.y / p.tiles_n : 0;
   const int tile_n = p.n_problems ? blockIdx.y % p.tiles_n : blockIdx.y;
   const int m0 = blockIdx.x * BM, n0 = tile_n * BN;
-  // select with ternaries: a runtime index into the by-value argument struct would move the
-  // whole struct to scratch memory
   const float* a_first = p.a[0];
   const float* b_first = p.b[0];
   if (p.n_problems) {
-    a_first = problem == 0 ? p.pa[0] : problem == 1 ? p.pa[1] : problem == 2 ? p.pa[2] : p.pa[3];
-    b_first = problem == 0 ? p.pb[0] : problem == 1 ? p.pb[1] : problem == 2 ? p.pb[2] : p.pb[3];
+    a_first = kernarg_entry<const float*>(offsetof(GemmArgs, pa), problem);
+    b_first = kernarg_entry<const float*>(offsetof(GemmArgs, pb), problem);
   }
 
   const int nt0 = (p.kseg[0] + kBK - 1) / kBK;
@@ -349,7 +358,7 @@ void gemm_kernel(const GemmArgs p) {
 // out_q[i] = sum_s slab[q][s][i] for problems q, summed in split order inside four interleaved
 // split groups whose partials are then added in group order: a fixed association, so results
 // are bitwise reproducible.  One float4 column per thread-quad.
-struct ReduceArgs {   // up to 4 weight-slab jobs + 4 bias-slab jobs in one launch (blockIdx.y = job)
+struct ReduceArgs {   // weight-slab + bias-slab jobs of every problem in one launch (blockIdx.y = job)
   const float* slabs[2 * kMaxProblems];
   float* out[2 * kMaxProblems];
   int n4[2 * kMaxProblems];  // float4 per job
@@ -360,13 +369,9 @@ __global__ __launch_bounds__(kBlock) void reduce_slabs_kernel(const ReduceArgs p
   __shared__ v4f part[4][64];
   const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int q = blockIdx.y;
-  // ternary selection: no runtime index into the by-value argument struct (scratch memory)
-  const float* slabs = q == 0 ? p.slabs[0] : q == 1 ? p.slabs[1] : q == 2 ? p.slabs[2] : q == 3 ? p.slabs[3]
-                     : q == 4 ? p.slabs[4] : q == 5 ? p.slabs[5] : q == 6 ? p.slabs[6] : p.slabs[7];
-  float* out = q == 0 ? p.out[0] : q == 1 ? p.out[1] : q == 2 ? p.out[2] : q == 3 ? p.out[3]
-             : q == 4 ? p.out[4] : q == 5 ? p.out[5] : q == 6 ? p.out[6] : p.out[7];
-  const int n4 = q == 0 ? p.n4[0] : q == 1 ? p.n4[1] : q == 2 ? p.n4[2] : q == 3 ? p.n4[3]
-               : q == 4 ? p.n4[4] : q == 5 ? p.n4[5] : q == 6 ? p.n4[6] : p.n4[7];
+  const float* slabs = kernarg_entry<const float*>(offsetof(ReduceArgs, slabs), q);
+  float* out = kernarg_entry<float*>(offsetof(ReduceArgs, out), q);
+  const int n4 = kernarg_entry<int>(offsetof(ReduceArgs, n4), q);
   const int i = blockIdx.x * 64 + col;
   if (blockIdx.x * 64 >= n4) return;   // whole workgroup past this job's end
   v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -522,8 +527,7 @@ int g_fwd_variant = -1;    // forward kernels (both operands kk-contiguous); -1 
                            // workgroup per CU) when that fills >= 3/4 of the CUs, else 3 (64x256, two per CU);
                            // in-bench 748-754 graphs/s with 8 vs 738 with 3 (profiles/r01_tune_gemm.log)
 int g_igrad_variant = 1;   // input-gradient kernels (B kk-strided)
-int g_wgrad_variant = -1;  // split-reduction kernel; -1 = 1 (128x128 tiles, 8 waves): fastest for one problem and,
-                           // on a single stream, for the batch of three (789 graphs/s vs 777 with 2 = 128x256)
+int g_wgrad_variant = -1;  // split-reduction kernel; -1 = chosen per launch by wgrad_plan()
 
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, bool DB = false>
 int launch_tiles(const GemmArgs& p, int grid_y_mult, int splits, hipStream_t st) {
@@ -559,39 +563,53 @@ int launch_plain(const GemmArgs& p, hipStream_t st) {
   }
 }
 
-// tile edge lengths of the split-reduction variants (needed to size the workspace)
-inline int wgrad_variant(int n_problems) {
-  (void)n_problems;
-  return g_wgrad_variant >= 0 ? g_wgrad_variant : 1;
+// Split-reduction plan of a weight-gradient launch: tile variant, its edge lengths, and how many
+// ways the reduction over the M nodes is split (also sizes the workspace).
+struct WgradPlan {
+  int variant, bm, bn, splits;
+};
+
+inline void wgrad_candidate(int variant, int64_t k, int* bm, int* bn, int64_t* slots) {
+  *bm = 128, *bn = k <= 64 ? 64 : 128, *slots = 512;   // 2 workgroups per CU
+  if (k <= 64) return;
+  if (variant == 2) *bn = 256;
+  if (variant == 3) *bm = 64, *bn = 256;
+  if (variant == 4) *bm = 256, *bn = 256, *slots = 256;  // double-buffered: one workgroup per CU
 }
 
-inline void wgrad_tile(int64_t k, int n_problems, int* bm, int* bn) {
-  const int v = wgrad_variant(n_problems);
-  *bm = 128;
-  *bn = k <= 64 ? 64 : 128;
-  if (k > 64 && v == 2) *bn = 256;
-  if (k > 64 && v == 3) *bm = 64, *bn = 256;
-  if (k > 64 && v == 4) *bm = 256, *bn = 256;
-}
-
-inline int wgrad_splits(int64_t m, int64_t n, int64_t k, int n_problems) {
-  int bm, bn;
-  wgrad_tile(k, n_problems, &bm, &bn);
+inline WgradPlan wgrad_plan(int64_t m, int64_t n, int64_t k, int n_problems) {
   const int64_t tiles = (m + kBK - 1) / kBK;
-  const int64_t out_tiles = ((n + bm - 1) / bm) * ((k + bn - 1) / bn) * n_problems;
-  // 2 workgroups per CU = 512 slots (1 per CU for the double-buffered tiles); never one more
-  // workgroup than slots (a lone tail round)
-  const int v = wgrad_variant(n_problems);
-  const int64_t slots = (k > 64 && v == 4) ? 256 : 512;
-  int64_t splits = out_tiles >= slots ? 1 : slots / out_tiles;
-  if (splits > tiles) splits = tiles;
-  return static_cast<int>(splits < 1 ? 1 : splits);
+  // automatic (in-bench sweeps, profiles/r01_tune_gemm.log): up to 4 problems (one layer) ->
+  // 128x128 tiles (1): 42 splits of the three 256x256 problems fill 504 of 512 slots with half the
+  // slab traffic of the wider tiles.  More problems (a whole layer stack at once) -> of the
+  // double-buffered 256x256 tile (4) and the 128x256 tile (2), the one whose workgroup count
+  // (output tiles x splits, never more than the slots: no lone tail round) fills the chip best;
+  // 19 problems: variant 4, 13 splits, 247 of 256 slots, 144 reduction tiles per workgroup.
+  static const int kMany[2] = {4, 2};
+  const int n_candidates = g_wgrad_variant >= 0 || n_problems <= 4 ? 1 : 2;
+  WgradPlan best{};
+  double best_fill = -1.0;
+  for (int c = 0; c < n_candidates; ++c) {
+    WgradPlan plan{};
+    plan.variant = g_wgrad_variant >= 0 ? g_wgrad_variant : (n_problems <= 4 ? 1 : kMany[c]);
+    int64_t slots;
+    wgrad_candidate(plan.variant, k, &plan.bm, &plan.bn, &slots);
+    const int64_t out_tiles = ((n + plan.bm - 1) / plan.bm) * ((k + plan.bn - 1) / plan.bn) * n_problems;
+    int64_t splits = out_tiles >= slots ? 1 : slots / out_tiles;
+    if (splits > tiles) splits = tiles;
+    plan.splits = static_cast<int>(splits < 1 ? 1 : splits);
+    const int64_t groups = out_tiles * plan.splits;
+    const int64_t rounds = (groups + slots - 1) / slots;
+    const double fill = static_cast<double>(groups) / static_cast<double>(rounds * slots);
+    if (fill > best_fill + 1e-9) best = plan, best_fill = fill;
+  }
+  return best;
 }
 
-int launch_wgrad(const GemmArgs& p, int splits, hipStream_t st) {
-  const int np = p.n_problems;
+int launch_wgrad(const GemmArgs& p, const WgradPlan& plan, hipStream_t st) {
+  const int np = p.n_problems, splits = plan.splits;
   if (p.rb <= 64) return launch_tiles<128, 64, 2, 2, false, false>(p, np, splits, st);
-  switch (wgrad_variant(np)) {
+  switch (plan.variant) {
     case 1: return launch_tiles<128, 128, 2, 4, false, false>(p, np, splits, st);
     case 2: return launch_tiles<128, 256, 2, 4, false, false>(p, np, splits, st);
     case 3: return launch_tiles<64, 256, 1, 4, false, false>(p, np, splits, st);
@@ -669,7 +687,7 @@ extern "C" int64_t gts_linear_bwd_weight_workspace(int64_t m, int64_t n, int64_t
                                                    int32_t n_problems) {
   using namespace gts;
   if (m <= 0 || n <= 0 || k <= 0 || n_problems < 1 || n_problems > kMaxProblems) return 0;
-  const int64_t splits = wgrad_splits(m, n, k, n_problems);
+  const int64_t splits = wgrad_plan(m, n, k, n_problems).splits;
   const int64_t slabs = n_problems * splits * (n * k + n);
   // the skinny path handles one problem at a time: [chunks][small+1][big] (+ [chunks][small] bias)
   const int64_t skinny = skinny_workspace_floats(m, n, k) + kSkinnyChunks * (n < k ? n : 0);
@@ -699,7 +717,8 @@ extern "C" int32_t gts_linear_bwd_weight_f32(const float* const* g, const float*
       skinny_wgrad(g[q], a[q], gw[q], gb ? gb[q] : nullptr, workspace, m, n, k, st);
     return launch_status();
   }
-  const int splits = wgrad_splits(m, n, k, n_problems);
+  const WgradPlan plan = wgrad_plan(m, n, k, n_problems);
+  const int splits = plan.splits;
   const int tiles = static_cast<int>((m + kBK - 1) / kBK);
   GemmArgs p{};
   // C[n, k] = sum_m g[m, n] * act[m, k]: both operands reduction-strided
@@ -712,7 +731,7 @@ extern "C" int32_t gts_linear_bwd_weight_f32(const float* const* g, const float*
   p.colsum = any_bias ? workspace + static_cast<size_t>(n_problems) * splits * n * k : nullptr;
   p.n_problems = n_problems, p.n_splits = splits;
   p.tiles_per_split = (tiles + splits - 1) / splits;
-  int rc = launch_wgrad(p, splits, st);
+  int rc = launch_wgrad(p, plan, st);
   if (rc != GTS_OK) return rc;
   // one reduction launch: weight slabs of every problem, then the bias slabs that were asked for
   ReduceArgs r{};

@@ -121,10 +121,18 @@ def linear_bwd_input(g0, w0, g1=None, w1=None, relu_mask=None):
     return gin if kp == k else gin[:, :k].contiguous()
 
 
+MAX_WGRAD_PROBLEMS = 32   # kMaxProblems of csrc/gts_gemm.hip
+
+
 def linear_bwd_weight_multi(problems):
-    """[(g [M,N], a [M,K], want_bias_grad), ...] (1..4 problems of ONE shape) ->
-    [(g^T @ a [N,K], column sums of g [N] or None), ...] in a single split-reduction launch."""
+    """[(g [M,N], a [M,K], want_bias_grad), ...] (problems of ONE shape) ->
+    [(g^T @ a [N,K], column sums of g [N] or None), ...]; up to 32 problems per split-reduction
+    launch (more are handled in groups)."""
     import ctypes
+
+    if len(problems) > MAX_WGRAD_PROBLEMS:
+        return (linear_bwd_weight_multi(problems[:MAX_WGRAD_PROBLEMS])
+                + linear_bwd_weight_multi(problems[MAX_WGRAD_PROBLEMS:]))
 
     n, k = problems[0][0].shape[1], problems[0][1].shape[1]
     gs = [_pad4_cols(g) for g, _, _ in problems]

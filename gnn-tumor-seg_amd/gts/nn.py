@@ -119,32 +119,48 @@ class _SagePoolStack(torch.autograd.Function):
         grads = [None] * (5 * n)
         g = gout.contiguous()            # gradient w.r.t. the pre-activation output of layer i
         gx = None
-        # The weight gradients are off the critical path (nothing in the backward chain reads
-        # them), so they go to a second, low-priority HIP stream: their workgroups fill the
-        # CUs that the chain's short GEMMs leave idle in their prologue / epilogue / last round.
+        # Nothing in the backward chain reads the weight gradients, so they are not computed layer
+        # by layer: every (gradient, activation) pair is kept and all problems of one shape go into
+        # ONE split-reduction launch at the end (the 256-wide layers of C2: 19 problems).  Few long
+        # reductions per workgroup instead of many short ones, one slab reduction instead of seven.
+        # (GTS_OVERLAP_WGRAD=1 restores the older scheme: per-layer launches on a second,
+        # low-priority stream.)
         main = torch.cuda.current_stream()
         side = _side_stream(g.device) if OVERLAP_WEIGHT_GRADS else None
         keep_alive = []
+        deferred = {}                    # (N, K) -> [(g [M,N], a [M,K], want_bias, grads slot, bias slot)]
+
+        def defer(grad_out, act, slot, bias_slot):
+            key = (grad_out.shape[1], act.shape[1])
+            deferred.setdefault(key, []).append((grad_out, act, bias_slot is not None, slot, bias_slot))
+
         for i in reversed(range(n)):
             h, p, m, arg = acts[4 * i:4 * i + 4]
             w_pool, _b_pool, w_self, w_neigh, _bias = params[5 * i:5 * i + 5]
             gm = dense.linear_bwd_input(g, w_neigh)
             gp = ops.spmm_max_bwd(ctx.g, gm, arg, relu_src=p)
             if side is None:
-                layer_grads = _pool_layer_weight_grads(g, gp, h, m, w_pool, w_self)
+                defer(gp, h, 5 * i, 5 * i + 1)          # fc_pool.weight, fc_pool.bias
+                defer(g, h, 5 * i + 2, 5 * i + 4)       # fc_self.weight, bias
+                defer(g, m, 5 * i + 3, None)            # fc_neigh.weight
             else:
                 ready = torch.cuda.Event()
                 ready.record(main)                      # g and gp are complete on the main stream
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
-                    layer_grads = _pool_layer_weight_grads(g, gp, h, m, w_pool, w_self)
+                    g_ws, g_wn, g_wp, g_bias, g_bp = _pool_layer_weight_grads(g, gp, h, m, w_pool, w_self)
                 keep_alive.append((g, gp))              # still being read by the side stream
-            g_ws, g_wn, g_wp, g_bias, g_bp = layer_grads
-            grads[5 * i:5 * i + 5] = [g_wp, g_bp, g_ws, g_wn, g_bias]
+                grads[5 * i:5 * i + 5] = [g_wp, g_bp, g_ws, g_wn, g_bias]
             if i > 0:      # h is layer i-1's ReLU output: its backward is the mask h > 0
                 g = dense.linear_bwd_input(g, w_self, gp, w_pool, relu_mask=h)
             elif ctx.needs_input_grad[1]:
                 gx = dense.linear_bwd_input(g, w_self, gp, w_pool)
+        for problems in deferred.values():
+            results = dense.linear_bwd_weight_multi([(go, act, want) for go, act, want, _, _ in problems])
+            for (gw, gb), (_, _, _, slot, bias_slot) in zip(results, problems):
+                grads[slot] = gw
+                if bias_slot is not None:
+                    grads[bias_slot] = gb
         if side is not None:
             main.wait_stream(side)
             for t in grads:

@@ -208,8 +208,8 @@ int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const float* a1, co
 int32_t gts_linear_bwd_input_f32(const float* g0, const float* w0, const float* g1, const float* w1,
                                  const float* relu_mask, float* gin, int64_t m, int64_t k,
                                  int64_t n0, int64_t n1, void* stream);
-/* weight gradients of n_problems (1..4) same-shape problems in ONE launch (the three weight
- * gradients of a SAGE layer):  gw[q][n, k] = sum_m g[q][m,n] a[q][m,k];
+/* weight gradients of n_problems (1..32) same-shape problems in ONE launch (the three weight
+ * gradients of a SAGE layer, or those of a whole stack of equal layers):  gw[q][n, k] = sum_m g[q][m,n] a[q][m,k];
  * gb[q][n] = sum_m g[q][m,n] where gb && gb[q].  g, a, gw, gb are HOST arrays of device pointers.
  *   The reduction over the M nodes is split over workgroups into slabs in `workspace`
  *   (>= gts_linear_bwd_weight_workspace(m,n,k,n_problems) bytes, caller-owned scratch) that a

@@ -112,6 +112,24 @@ def test_linear_weight_and_bias_gradient(m, k, n):
     assert none is None and torch.equal(gw2, gw)          # bitwise reproducible (fixed-order slabs)
 
 
+@pytest.mark.parametrize("m,n,k,count", [(3000, 256, 256, 19), (777, 128, 132, 5), (500, 64, 64, 35)])
+def test_many_weight_gradients_in_one_launch(m, n, k, count):
+    """A whole layer stack's weight gradients (19 problems of one shape at C2) in one
+    split-reduction launch; more than 32 problems are handled in groups.  Distinct operands per
+    problem, bias gradients for every other one, each checked against fp64."""
+    gs = [_rand(m, n, seed=100 + q) for q in range(count)]
+    acts = [_rand(m, k, seed=200 + q) for q in range(count)]
+    out = dense.linear_bwd_weight_multi([(g.to(DEV), a.to(DEV), q % 2 == 0) for q, (g, a) in enumerate(zip(gs, acts))])
+    assert len(out) == count
+    for q, ((gw, gb), g, a) in enumerate(zip(out, gs, acts)):
+        _check(gw, g.double().t() @ a.double(), g.double().abs().t() @ a.double().abs())
+        assert (gb is not None) == (q % 2 == 0)
+        if gb is not None:
+            _check(gb, g.double().sum(0), g.double().abs().sum(0))
+    again = dense.linear_bwd_weight_multi([(g.to(DEV), a.to(DEV), False) for g, a in zip(gs, acts)])
+    assert all(torch.equal(x[0], y[0]) for x, y in zip(out, again))      # fixed-order slabs: reproducible
+
+
 def test_linear_autograd_matches_torch():
     x = _rand(333, 20, seed=1).to(DEV).requires_grad_(True)
     w = _rand(64, 20, seed=2).to(DEV).requires_grad_(True)

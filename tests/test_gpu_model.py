@@ -329,7 +329,8 @@ def test_rccl_world_size_one_flat_gradient_path():
 
 @pytest.mark.parametrize("hp", [HP(4, 4, [256] * 3, None, None), HP(20, 4, [64, 32], None, None)])
 def test_fused_pool_stack_equals_layer_by_layer_path(hp):
-    """The fused stack only moves the ReLU backward into a GEMM epilogue: bitwise identical."""
+    """The fused stack moves the ReLU backward into a GEMM epilogue (logits and input gradients are
+    bitwise identical) and batches the weight gradients of all layers into one launch."""
     src, dst = random_coo(700, 4000, seed=3)
     g = gts.Graph(src, dst, 700).to(DEV)
     _, fused = _net_pair("GSpool", hp, seed=11)
@@ -345,8 +346,10 @@ def test_fused_pool_stack_equals_layer_by_layer_path(hp):
         outs.append((logits.detach(), xi.grad, [p.grad for p in net.parameters()]))
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
+    # the stack sums each weight gradient's node reduction in fewer, longer splits (all layers in
+    # one launch) than the per-layer path: same terms, different association
     for a, b in zip(outs[0][2], outs[1][2]):
-        assert torch.equal(a, b)
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * max(1.0, float(b.abs().max())))
     with torch.no_grad():
         assert torch.equal(fused(g, x), outs[0][0])          # inference path (no argmax written)
     plain.layers[0].feat_drop.p = 0.5                          # active dropout -> stack declines
