@@ -76,6 +76,7 @@ __global__ __launch_bounds__(kBlock) void sum_chunks_kernel(const float* __restr
   const int q = blockIdx.x * 16 + cg;
   v4f acc = {0.f, 0.f, 0.f, 0.f};
   if (q < (cols >> 2)) {
+#pragma unroll 8   // independent loads, issued back to back (the adds keep their order)
     for (int b = lane; b < chunks; b += 16)
       acc += *reinterpret_cast<const v4f*>(partial + static_cast<size_t>(b) * cols + 4 * q);
   }

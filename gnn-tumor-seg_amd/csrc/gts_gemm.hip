@@ -452,8 +452,10 @@ __global__ __launch_bounds__(kBlock) void skinny_sum_kernel(const float* __restr
   const int idx = blockIdx.x * 16 + o;
   const int total_out = rows * w;
   float acc = 0.f;
-  if (idx < total_out)
+  if (idx < total_out) {
+#pragma unroll 8   // independent loads, issued back to back (the adds keep their order)
     for (int c = lane; c < chunks; c += 16) acc += partial[static_cast<size_t>(c) * total_out + idx];
+  }
   part[lane][o] = acc;
   __syncthreads();
   if (lane != 0 || idx >= total_out) return;
