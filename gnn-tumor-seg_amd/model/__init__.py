@@ -1,0 +1,1 @@
+"""Networks, training harness and metrics on the MI355X HIP path."""
