@@ -135,5 +135,13 @@ def minibatch_graphs(samples):
     """Collate [(id, graph, feats, labels), ...] into one block-diagonal batch
     (reference data_loader.py:165-169)."""
     mri_ids, graphs, features, labels = map(list, zip(*samples))
-    return (mri_ids, gts.batch(graphs), torch.FloatTensor(np.concatenate(features)),
-            torch.LongTensor(np.concatenate(labels)))
+    # same values as torch.FloatTensor(np.concatenate(features)): each float64 block is rounded to
+    # fp32 while it is copied into place (one pass instead of concatenate-then-convert)
+    rows = [np.asarray(f) for f in features]
+    feats = np.empty((sum(len(f) for f in rows),) + rows[0].shape[1:], dtype=np.float32)
+    at = 0
+    for f in rows:
+        feats[at:at + len(f)] = f
+        at += len(f)
+    return (mri_ids, gts.batch(graphs), torch.from_numpy(feats),
+            torch.from_numpy(np.concatenate(labels).astype(np.int64, copy=False)))

@@ -23,39 +23,53 @@ _I32_MAX = 2 ** 31 - 1
 
 
 class _DeviceCSR:
-    """Device-resident int32 arrays + degree vectors of one Graph."""
+    """Device-resident int32 arrays + degree vectors of one Graph, uploaded as ONE packed buffer
+    (a single host->device copy instead of eight) and handed out as views of it."""
 
     __slots__ = ("indptr", "indices", "t_indptr", "t_indices", "t_slot", "t_pos",
-                 "deg_clamped", "deg_plus1", "device")
+                 "deg_clamped", "deg_plus1", "device", "packed")
+    _INT_FIELDS = ("indptr", "indices", "t_indptr", "t_indices", "t_slot", "t_pos")
 
     def __init__(self, g, device):
-        def up(a):
-            return torch.from_numpy(a).to(device, non_blocking=False)
-
-        self.device = device
-        self.indptr = up(g.indptr)
-        self.indices = up(g.indices)
-        self.t_indptr = up(g.t_indptr)
-        self.t_indices = up(g.t_indices)
-        self.t_slot = up(g.t_slot)
-        self.t_pos = up(g.t_pos)
         deg = np.diff(g.indptr).astype(np.float32)
-        self.deg_clamped = up(np.maximum(deg, np.float32(1)))
-        self.deg_plus1 = up(deg + np.float32(1))
+        parts = [np.ascontiguousarray(getattr(g, name), dtype=np.int32) for name in self._INT_FIELDS]
+        parts += [np.maximum(deg, np.float32(1)).view(np.int32), (deg + np.float32(1)).view(np.int32)]
+        offsets, at = [], 0
+        for a in parts:                                  # every segment starts 16-byte aligned
+            offsets.append(at)
+            at += (a.size + 3) & ~3
+        host = np.empty(max(at, 4), dtype=np.int32)
+        for a, off in zip(parts, offsets):
+            host[off:off + a.size] = a
+        self.device = device
+        self.packed = torch.from_numpy(host).to(device)
+        views = [self.packed[off:off + a.size] for a, off in zip(parts, offsets)]
+        for name, v in zip(self._INT_FIELDS, views):
+            setattr(self, name, v)
+        self.deg_clamped = views[6].view(torch.float32)
+        self.deg_plus1 = views[7].view(torch.float32)
+
+    def record_stream(self, stream):
+        """The buffer was uploaded on another stream than the one that will read it."""
+        self.packed.record_stream(stream)
 
 
 class Graph:
-    def __init__(self, src, dst, num_nodes, batch_num_nodes=None, _prebuilt=None):
-        self.src = np.ascontiguousarray(src, dtype=np.int32)
-        self.dst = np.ascontiguousarray(dst, dtype=np.int32)
+    def __init__(self, src, dst, num_nodes, batch_num_nodes=None, _prebuilt=None, _members=None):
         self.n = int(num_nodes)
-        if self.src.shape != self.dst.shape or self.src.ndim != 1:
-            raise ValueError("src/dst must be 1-D arrays of equal length")
-        if self.n > _I32_MAX or self.src.size > _I32_MAX:
-            raise ValueError("graph too large for int32 CSR")
-        if self.src.size and (min(self.src.min(), self.dst.min()) < 0 or
-                              max(self.src.max(), self.dst.max()) >= self.n):
-            raise ValueError("edge endpoint outside [0, num_nodes)")
+        self._members = _members          # batch(): COO is assembled from the members on first use
+        if _members is None:
+            self._src = np.ascontiguousarray(src, dtype=np.int32)
+            self._dst = np.ascontiguousarray(dst, dtype=np.int32)
+            if self._src.shape != self._dst.shape or self._src.ndim != 1:
+                raise ValueError("src/dst must be 1-D arrays of equal length")
+            if self.n > _I32_MAX or self._src.size > _I32_MAX:
+                raise ValueError("graph too large for int32 CSR")
+            if self._src.size and (min(self._src.min(), self._dst.min()) < 0 or
+                                   max(self._src.max(), self._dst.max()) >= self.n):
+                raise ValueError("edge endpoint outside [0, num_nodes)")
+        else:
+            self._src = self._dst = None  # members were validated when they were built
         self._batch_num_nodes = list(batch_num_nodes) if batch_num_nodes is not None else [self.n]
         self.ndata = {}
         self.device = torch.device("cpu")
@@ -68,6 +82,23 @@ class Graph:
         deg = np.diff(self.indptr)
         self.max_in_degree = int(deg.max()) if deg.size else 0
         self.min_in_degree = int(deg.min()) if deg.size else 0
+
+    def _coo(self):
+        if self._src is None:
+            graphs, node_off = self._members
+            self._src = np.concatenate([g.src + node_off[i] for i, g in enumerate(graphs)]).astype(np.int32, copy=False)
+            self._dst = np.concatenate([g.dst + node_off[i] for i, g in enumerate(graphs)]).astype(np.int32, copy=False)
+            self._members = None
+        return self._src, self._dst
+
+    @property
+    def src(self):
+        """COO sources in edge order (int32)."""
+        return self._coo()[0]
+
+    @property
+    def dst(self):
+        return self._coo()[1]
 
     # ------------------------------------------------------------------ construction
     def _build_csr(self):
@@ -95,7 +126,7 @@ class Graph:
     num_nodes = number_of_nodes
 
     def number_of_edges(self):
-        return int(self.src.size)
+        return int(self.indices.size)
 
     num_edges = number_of_edges
 
@@ -192,23 +223,30 @@ def batch(graphs):
         raise ValueError("batched graph too large for int32 CSR")
     no32 = node_off.astype(np.int32)
     eo32 = edge_off.astype(np.int32)
+    n_total, e_total = int(node_off[-1]), int(edge_off[-1])
 
+    # one pass per array: every member slice is written (shifted) straight into its place
     def cat_ptr(name):
-        parts = [getattr(g, name)[:-1] + eo32[i] for i, g in enumerate(graphs)]
-        parts.append(np.array([eo32[-1]], dtype=np.int32))
-        return np.concatenate(parts).astype(np.int32, copy=False)
+        out = np.empty(n_total + 1, dtype=np.int32)
+        for i, g in enumerate(graphs):
+            np.add(getattr(g, name)[:-1], eo32[i], out=out[node_off[i]:node_off[i + 1]])
+        out[n_total] = eo32[-1]
+        return out
 
-    def cat_nodes(name):
-        return np.concatenate([getattr(g, name) + no32[i] for i, g in enumerate(graphs)])
+    def cat_edges(name, shift):
+        out = np.empty(e_total, dtype=np.int32)
+        for i, g in enumerate(graphs):
+            part = out[edge_off[i]:edge_off[i + 1]]
+            if shift is None:
+                part[:] = getattr(g, name)
+            else:
+                np.add(getattr(g, name), shift[i], out=part)
+        return out
 
-    prebuilt = (
-        cat_ptr("indptr"), cat_nodes("indices"), cat_ptr("t_indptr"), cat_nodes("t_indices"),
-        np.concatenate([g.t_slot for g in graphs]),
-        np.concatenate([g.t_pos + eo32[i] for i, g in enumerate(graphs)]),
-    )
+    prebuilt = (cat_ptr("indptr"), cat_edges("indices", no32), cat_ptr("t_indptr"), cat_edges("t_indices", no32),
+                cat_edges("t_slot", None), cat_edges("t_pos", eo32))
     sizes = [s for g in graphs for s in g._batch_num_nodes]
-    out = Graph(cat_nodes("src"), cat_nodes("dst"), int(node_off[-1]), batch_num_nodes=sizes,
-                _prebuilt=tuple(np.ascontiguousarray(a, dtype=np.int32) for a in prebuilt))
+    out = Graph(None, None, n_total, batch_num_nodes=sizes, _prebuilt=prebuilt, _members=(graphs, no32))
     common = set(graphs[0].ndata)
     for g in graphs[1:]:
         common &= set(g.ndata)

@@ -12,7 +12,9 @@ Differences that do not change results:
     `torch.optim.Optimizer` with the same update rule and a single param group);
   * `ExponentialLR(..., verbose=False)` (reference :29) raises on current PyTorch; the kwarg
     is dropped, behaviour is the same;
-  * the per-step `loss.item()` host sync (:43) becomes one read-back per epoch (same values);
+  * the per-step `loss.item()` host sync (:43) becomes one read-back per epoch (same values), and
+    the next batch is collated and uploaded by a worker thread while the current step runs
+    (`prefetch=True`; same batches, same order);
   * when torch.distributed is initialised with world_size > 1, every rank trains on its
     share of each global batch and gradients are combined by gts.dist.FlatGradSync (exact
     weighted-CE normalisation); world_size == 1 follows the reference's arithmetic exactly.
@@ -54,10 +56,11 @@ class _ShardedBatches:
 
 
 class GNN:
-    def __init__(self, model_type, hyperparameters, train_dataset, batch_size=BATCH_SIZE):
+    def __init__(self, model_type, hyperparameters, train_dataset, batch_size=BATCH_SIZE, prefetch=True):
         if not torch.cuda.is_available():
             raise RuntimeError("GNN needs an AMD GPU (MI355X): the HIP kernels have no CPU fallback")
         self.rank, self.world_size = gdist.world()
+        self.prefetch = prefetch
         self.device = torch.device("cuda", torch.cuda.current_device())
         print("Using device", self.device)
         class_weights = torch.FloatTensor(hyperparameters.class_weights).to(self.device)
@@ -113,12 +116,67 @@ class GNN:
             if not isinstance(labels, torch.Tensor) else labels.to(self.device, torch.int64)
         return graph, features, labels
 
+    def _device_batches(self):
+        """The loader's batches, already on the GPU, prepared one step ahead: a worker thread
+        collates batch i+1 (JSON / cache read, block-diagonal union) and uploads it on a copy
+        stream while the main thread enqueues step i.  Same batches in the same order as iterating
+        the loader directly (`prefetch=False`)."""
+        if not self.prefetch:
+            for _ids, graph, feats, labels in self.train_loader:
+                yield self._to_device(graph, feats, labels)
+            return
+        import queue
+        import threading
+
+        slots, stop = queue.Queue(maxsize=2), threading.Event()
+        copy_stream = torch.cuda.Stream(device=self.device)
+        device_index = self.device.index
+
+        def produce():
+            try:
+                torch.cuda.set_device(device_index)
+                for _ids, graph, feats, labels in self.train_loader:
+                    if stop.is_set():
+                        return
+                    with torch.cuda.stream(copy_stream):
+                        batch = self._to_device(graph, feats, labels)
+                        batch[0].dev()                     # CSR upload belongs to the copy as well
+                        ready = torch.cuda.Event()
+                        ready.record(copy_stream)
+                    slots.put((batch, ready))
+                slots.put(None)
+            except BaseException as exc:                   # noqa: BLE001 - re-raised in the consumer
+                slots.put(exc)
+
+        worker = threading.Thread(target=produce, name="gts-batch-prefetch", daemon=True)
+        worker.start()
+        try:
+            while True:
+                item = slots.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                (graph, feats, labels), ready = item
+                main = torch.cuda.current_stream()
+                main.wait_event(ready)
+                graph.dev().record_stream(main)            # allocated on the copy stream, read here
+                feats.record_stream(main)
+                labels.record_stream(main)
+                yield graph, feats, labels
+        finally:
+            stop.set()
+            while worker.is_alive():                       # unblock a producer waiting on a full queue
+                try:
+                    slots.get_nowait()
+                except queue.Empty:
+                    worker.join(timeout=0.05)
+
     def run_epoch(self):
         """One pass over the training loader; returns the mean of the per-step losses
         (reference :34-48).  Losses stay on the device until the epoch ends."""
         self.net.train()
-        step_losses = [self.train_step(*self._to_device(graph, feats, labels))
-                       for _ids, graph, feats, labels in self.train_loader]
+        step_losses = [self.train_step(graph, feats, labels) for graph, feats, labels in self._device_batches()]
         self.lr_decay.step()
         return np.mean(torch.stack(step_losses).cpu().double().numpy())
 

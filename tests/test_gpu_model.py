@@ -509,3 +509,38 @@ def test_reference_hardcoded_gat_defaults_are_inconsistent_and_fail_loudly():
     g = gts.Graph(np.concatenate([src, np.arange(60)]), np.concatenate([dst, np.arange(60)]), 60).to(DEV)
     with pytest.raises(gts.GtsError, match="shapes do not match"):
         net(g, torch.randn(60, 20, device=DEV))
+
+
+def test_prefetched_epochs_equal_plain_epochs_and_errors_surface():
+    """run_epoch with the batch-prefetch thread (collate + upload one step ahead on a copy
+    stream) gives bit-identical epoch losses and weights to iterating the loader in line; an
+    exception inside the dataset reaches the caller."""
+    from model.gnn_model import GNN
+    from utils.hyperparam_helpers import FullParamSet
+
+    hp = FullParamSet(3, 20, 4, 1e-3, 0.98, 1e-4, [0.1, 1, 2, 2], [64, 64], 0, None, None)
+    results = []
+    for prefetch in (True, False):
+        torch.manual_seed(5)
+        model = GNN("GSpool", hp, _MemDataset(14), batch_size=3, prefetch=prefetch)
+        losses = [model.run_epoch() for _ in range(3)]
+        results.append((losses, [p.detach().clone() for p in model.net.parameters()]))
+    assert results[0][0] == results[1][0]
+    assert all(torch.equal(a, b) for a, b in zip(results[0][1], results[1][1]))
+
+    class Broken(_MemDataset):
+        def __getitem__(self, i):
+            if i == 5:
+                raise KeyError("sample 5 is unreadable")
+            return super().__getitem__(i)
+
+    torch.manual_seed(5)
+    model = GNN("GSpool", hp, Broken(9), batch_size=3)
+    with pytest.raises(KeyError, match="unreadable"):
+        model.run_epoch()
+    # abandoning an epoch half way (consumer stops early) must not leave the producer stuck
+    model = GNN("GSpool", hp, _MemDataset(12), batch_size=2)
+    batches = model._device_batches()
+    next(batches)
+    batches.close()
+    assert np.isfinite(model.run_epoch())
