@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""End-to-end epoch throughput of GNN.run_epoch on in-memory samples (collate + upload + step),
+with and without the batch-prefetch thread, next to bench.py's resident-batch figure.
+  python tools/measure_epoch_throughput.py [--samples 48] [--batch 4] [--nodes-kind lattice]"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "gnn-tumor-seg_amd")):
+    sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from gts import synth  # noqa: E402
+from model.gnn_model import GNN  # noqa: E402
+
+
+class MemDataset(torch.utils.data.Dataset):
+    def __init__(self, n, kind):
+        self.items = [synth.make_sample(i, kind=kind, in_feats=bench.IN_FEATS) for i in range(n)]
+        self.items = [(f"s{i}", g, f.astype("float64"), y) for i, (_, g, f, y) in enumerate(self.items)]
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--samples", type=int, default=48)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--graph-kind", default="lattice")
+    args = ap.parse_args()
+    data = MemDataset(args.samples, args.graph_kind)
+    cfg = bench.CONFIGS["c2"]
+    for prefetch in (False, True, False, True):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(sys.stderr):
+            model = GNN(cfg["model"], bench.hyperparams(cfg), data, batch_size=args.batch, prefetch=prefetch)
+        model.run_epoch()                                   # warm-up epoch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = model.run_epoch()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        steps = len(model.train_loader)
+        print(json.dumps({"prefetch": prefetch, "graphs_per_s": round(steps * args.batch / dt, 1),
+                          "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "epoch_loss": float(loss)}),
+              flush=True)
+
+
+if __name__ == "__main__":
+    main()
