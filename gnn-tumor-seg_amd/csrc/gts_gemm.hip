@@ -554,14 +554,11 @@ int launch_plain(const GemmArgs& p, hipStream_t st) {
     variant = big_tiles >= 192 ? 8 : 3;
   }
   switch (variant) {
-    case 1: return launch_tiles<128, 256, 2, 4, AKC, BKC>(p, 1, 1, st);
-    case 2: return launch_tiles<64, 256, 1, 4, AKC, BKC>(p, 1, 1, st);
+    // the variants that survived the sweeps in profiles/r01_tune_gemm.log (numbers kept from there)
     case 3: return launch_tiles<64, 256, 2, 4, AKC, BKC>(p, 1, 1, st);
-    case 4: return launch_tiles<128, 128, 2, 2, AKC, BKC>(p, 1, 1, st);
     case 5: return launch_tiles<256, 128, 4, 2, AKC, BKC>(p, 1, 1, st);
-    case 7: return launch_tiles<256, 256, 2, 4, AKC, BKC, true>(p, 1, 1, st);
     case 8: return launch_tiles<256, 256, 4, 4, AKC, BKC, true>(p, 1, 1, st);
-    default: return launch_tiles<128, 256, 2, 2, AKC, BKC>(p, 1, 1, st);
+    default: return launch_tiles<128, 256, 2, 4, AKC, BKC>(p, 1, 1, st);   // 1
   }
 }
 
@@ -575,7 +572,6 @@ inline void wgrad_candidate(int variant, int64_t k, int* bm, int* bn, int64_t* s
   *bm = 128, *bn = k <= 64 ? 64 : 128, *slots = 512;   // 2 workgroups per CU
   if (k <= 64) return;
   if (variant == 2) *bn = 256;
-  if (variant == 3) *bm = 64, *bn = 256;
   if (variant == 4) *bm = 256, *bn = 256, *slots = 256;  // double-buffered: one workgroup per CU
 }
 
@@ -612,11 +608,9 @@ int launch_wgrad(const GemmArgs& p, const WgradPlan& plan, hipStream_t st) {
   const int np = p.n_problems, splits = plan.splits;
   if (p.rb <= 64) return launch_tiles<128, 64, 2, 2, false, false>(p, np, splits, st);
   switch (plan.variant) {
-    case 1: return launch_tiles<128, 128, 2, 4, false, false>(p, np, splits, st);
     case 2: return launch_tiles<128, 256, 2, 4, false, false>(p, np, splits, st);
-    case 3: return launch_tiles<64, 256, 1, 4, false, false>(p, np, splits, st);
     case 4: return launch_tiles<256, 256, 4, 4, false, false, true>(p, np, splits, st);
-    default: return launch_tiles<128, 128, 2, 2, false, false>(p, np, splits, st);
+    default: return launch_tiles<128, 128, 2, 4, false, false>(p, np, splits, st);   // 1
   }
 }
 

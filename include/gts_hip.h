@@ -236,9 +236,9 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
 /* ---- tuning knobs -----------------------------------------------------------------------
  * Process-wide tile selection of the K11 kernels (defaults are the tuned values; used by
  * tools/tune_gemm.py).  Returns GTS_ERR_ARGKIND for an unknown option. */
-#define GTS_OPT_GEMM_TILE 1  /* forward tile variant (-1 = automatic) */
-#define GTS_OPT_WGRAD_TILE 2 /* weight-gradient tile variant (-1 = automatic) */
-#define GTS_OPT_IGRAD_TILE 3 /* input-gradient tile variant */
+#define GTS_OPT_GEMM_TILE 1  /* forward tile: -1 automatic, 1 = 128x256, 3 = 64x256, 5 = 256x128, 8 = 256x256 double-buffered */
+#define GTS_OPT_WGRAD_TILE 2 /* weight-gradient tile: -1 automatic, 1 = 128x128, 2 = 128x256, 4 = 256x256 double-buffered */
+#define GTS_OPT_IGRAD_TILE 3 /* input-gradient tile: same numbering as the forward one (default 1) */
 #define GTS_OPT_PROJECT_STREAMING 6  /* K12: non-temporal stores of the projected rows (default 1) */
 #define GTS_OPT_SPMM_ROWS_PER_WAVE 4 /* K1-K4: rows one wave walks (0 = automatic) */
 #define GTS_OPT_SPMM_STREAMING 5     /* K1/K2: bit 0 = non-temporal stores of write-once rows, bit 1 = non-temporal
