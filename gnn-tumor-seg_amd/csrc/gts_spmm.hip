@@ -78,7 +78,7 @@ template <int VEC, int LPR, int ARGB>
 __global__ __launch_bounds__(kBlock) void spmm_max_fwd_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const float* __restrict__ x, float* __restrict__ out, void* __restrict__ arg, int n_dst,
-    int n_feat, int seq, int nt) {
+    int n_feat, int seq, int nt, int relu_input) {
   for (int s = 0; s < seq; ++s) {
     const int v = owned_row<LPR>(s, seq, n_dst);
     if (v < 0) continue;
@@ -110,7 +110,9 @@ __global__ __launch_bounds__(kBlock) void spmm_max_fwd_kernel(
       for (int t = 0; t < VEC; ++t) {
         const bool dead = isinf(best[t]);  // empty row (-inf) or a +-inf maximum -> 0, no winner
         o.v[t] = dead ? 0.0f : best[t];
-        slot[t] = dead ? -1 : slot[t];
+        // x = relu(.): a maximum that is not positive carries no gradient (relu'(0) = 0), so it
+        // is recorded as "no winner" and the backward never has to look at x again
+        slot[t] = (dead || (relu_input && !(best[t] > 0.0f))) ? -1 : slot[t];
       }
       const size_t off = static_cast<size_t>(v) * n_feat + c;
       if (active) {
@@ -228,8 +230,8 @@ __global__ __launch_bounds__(kBlock) void spmm_sum_kernel(
 
 extern "C" int32_t gts_spmm_max_fwd_f32(const int32_t* indptr, const int32_t* indices,
                                         const float* x, float* out, void* arg,
-                                        int32_t arg_bytes, int64_t n_dst, int64_t n_feat,
-                                        void* stream) {
+                                        int32_t arg_bytes, int32_t relu_input, int64_t n_dst,
+                                        int64_t n_feat, void* stream) {
   using namespace gts;
   if (!indptr || !x || !out || (arg_bytes != 0 && !arg)) return GTS_ERR_NULL;
   if (bad_shape(n_dst, n_feat)) return GTS_ERR_SHAPE;
@@ -241,11 +243,11 @@ extern "C" int32_t gts_spmm_max_fwd_f32(const int32_t* indptr, const int32_t* in
   const int nd = static_cast<int>(n_dst), nf = static_cast<int>(n_feat);
   GTS_DISPATCH_GEOM(g, {
     if (arg_bytes == 0)
-      spmm_max_fwd_kernel<VEC, LPR, 0><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, arg, nd, nf, g.seq, nt);
+      spmm_max_fwd_kernel<VEC, LPR, 0><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, arg, nd, nf, g.seq, nt, relu_input);
     else if (arg_bytes == 1)
-      spmm_max_fwd_kernel<VEC, LPR, 1><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, arg, nd, nf, g.seq, nt);
+      spmm_max_fwd_kernel<VEC, LPR, 1><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, arg, nd, nf, g.seq, nt, relu_input);
     else
-      spmm_max_fwd_kernel<VEC, LPR, 4><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, arg, nd, nf, g.seq, nt);
+      spmm_max_fwd_kernel<VEC, LPR, 4><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, arg, nd, nf, g.seq, nt, relu_input);
   })
   return launch_status();
 }

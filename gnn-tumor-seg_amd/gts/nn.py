@@ -8,7 +8,7 @@ libgts_hip.so (neighbour reducers, attention) plus dense fp32 GEMMs.
 
 The pool layer is ONE autograd node (`_SagePoolLayer`): forward and backward are written
 out by hand so that the ReLU of fc_pool is folded into the max-pool backward kernel, the
-argmax is kept as one byte per element, and nothing but (h, p, m, arg, out) is retained.
+argmax is kept as one byte per element, and nothing but (h, m, arg, out) is retained.
 """
 import os
 
@@ -34,21 +34,22 @@ class _SagePoolLayer(torch.autograd.Function):
     def forward(ctx, g, h, w_pool, b_pool, w_self, w_neigh, bias, relu_out, need_bwd):
         h = h.contiguous()
         p = dense.linear_fwd(h, w_pool, bias=b_pool, relu=True)
-        m, arg = ops.spmm_max_fwd(g, p, want_arg=need_bwd)
+        # relu_input: K1 keeps no winner where the maximum is not positive, which IS ReLU'(p) for
+        # the backward; p itself is not retained
+        m, arg = ops.spmm_max_fwd(g, p, want_arg=need_bwd, relu_input=True)
         out = dense.linear_fwd(h, w_self, m, w_neigh, bias=bias, relu=relu_out)
         if need_bwd:
             ctx.g, ctx.relu_out = g, relu_out
-            ctx.save_for_backward(h, p, m, arg, out if relu_out else None,
-                                  w_pool, w_self, w_neigh)
+            ctx.save_for_backward(h, m, arg, out if relu_out else None, w_pool, w_self, w_neigh)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        h, p, m, arg, out, w_pool, w_self, w_neigh = ctx.saved_tensors
+        h, m, arg, out, w_pool, w_self, w_neigh = ctx.saved_tensors
         g = dense.relu_bwd(gout, out) if ctx.relu_out else gout.contiguous()
         need = ctx.needs_input_grad
         gm = dense.linear_bwd_input(g, w_neigh)
-        gp = ops.spmm_max_bwd(ctx.g, gm, arg, relu_src=p)      # fused ReLU'(p)
+        gp = ops.spmm_max_bwd(ctx.g, gm, arg)                  # ReLU'(p) is in the winner record
         g_ws, g_wn, g_wp, g_bias, g_bp = _pool_layer_weight_grads(g, gp, h, m, w_pool, w_self)
         gh = dense.linear_bwd_input(g, w_self, gp, w_pool) if need[1] else None   # one K=2N pass
         return None, gh, g_wp, g_bp, g_ws, g_wn, g_bias, None, None
@@ -102,9 +103,9 @@ class _SagePoolStack(torch.autograd.Function):
             w_pool, b_pool, w_self, w_neigh, bias = params[5 * i:5 * i + 5]
             last = i == n_layers - 1
             p = dense.linear_fwd(h, w_pool, bias=b_pool, relu=True)
-            m, arg = ops.spmm_max_fwd(g, p, want_arg=need_bwd)
+            m, arg = ops.spmm_max_fwd(g, p, want_arg=need_bwd, relu_input=True)   # p is not kept
             out = dense.linear_fwd(h, w_self, m, w_neigh, bias=bias, relu=not last)
-            saved += [h, p, m, arg]
+            saved += [h, m, arg]
             h = out
         if need_bwd:
             ctx.g, ctx.n_layers = g, n_layers
@@ -115,7 +116,7 @@ class _SagePoolStack(torch.autograd.Function):
     def backward(ctx, gout):
         n = ctx.n_layers
         tensors = ctx.saved_tensors
-        acts, params = tensors[:4 * n], tensors[4 * n:]
+        acts, params = tensors[:3 * n], tensors[3 * n:]
         grads = [None] * (5 * n)
         g = gout.contiguous()            # gradient w.r.t. the pre-activation output of layer i
         gx = None
@@ -135,10 +136,10 @@ class _SagePoolStack(torch.autograd.Function):
             deferred.setdefault(key, []).append((grad_out, act, bias_slot is not None, slot, bias_slot))
 
         for i in reversed(range(n)):
-            h, p, m, arg = acts[4 * i:4 * i + 4]
+            h, m, arg = acts[3 * i:3 * i + 3]
             w_pool, _b_pool, w_self, w_neigh, _bias = params[5 * i:5 * i + 5]
             gm = dense.linear_bwd_input(g, w_neigh)
-            gp = ops.spmm_max_bwd(ctx.g, gm, arg, relu_src=p)
+            gp = ops.spmm_max_bwd(ctx.g, gm, arg)       # ReLU'(p) is already in the winner record
             if side is None:
                 defer(gp, h, 5 * i, 5 * i + 1)          # fc_pool.weight, fc_pool.bias
                 defer(g, h, 5 * i + 2, 5 * i + 4)       # fc_self.weight, bias

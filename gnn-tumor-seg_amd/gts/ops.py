@@ -33,8 +33,10 @@ def _f32(*tensors):
 
 
 # ---------------------------------------------------------------- raw kernel calls
-def spmm_max_fwd(g, x, want_arg=True):
-    """K1.  x [N,F] -> (out [N,F], arg [N,F] slot ids or None)."""
+def spmm_max_fwd(g, x, want_arg=True, relu_input=False):
+    """K1.  x [N,F] -> (out [N,F], arg [N,F] slot ids or None).  relu_input: x is a ReLU output;
+    maxima that are not positive get no winner, so spmm_max_bwd on this arg yields the gradient
+    w.r.t. the pre-activation directly (no relu_src needed)."""
     x = x.contiguous()
     _f32(x)
     require_device(x)
@@ -49,7 +51,7 @@ def spmm_max_fwd(g, x, want_arg=True):
 
     def launch():
         return lib.gts_spmm_max_fwd_f32(ptr(d.indptr), ptr(d.indices), ptr(x), ptr(out), ptr(arg),
-                                        ab, n, f, current_stream())
+                                        ab, 1 if relu_input else 0, n, f, current_stream())
 
     code = _timed("spmm_max_fwd_f256", launch) if (f == 256 and want_arg) else launch()
     check(code, "gts_spmm_max_fwd_f32")

@@ -43,10 +43,13 @@ const char* gts_error_string(int32_t code);
  *   +-inf results and empty rows give 0 and select nothing.
  *   arg (optional, arg_bytes = 0 -> not written): the SLOT k of the winner inside
  *   row v, as uint8 (arg_bytes=1, slot 0xFF = none; needs max in-degree <= 254)
- *   or int32 (arg_bytes=4, -1 = none); layout [n_dst, n_feat]. */
+ *   or int32 (arg_bytes=4, -1 = none); layout [n_dst, n_feat].
+ *   relu_input != 0: x is a ReLU output (SAGEConv-pool: x = relu(fc_pool(h))); a maximum that
+ *   is not positive is recorded as "none", because relu'(0) = 0 stops its gradient anyway — the
+ *   backward (K2) then gives the gradient w.r.t. the PRE-activation without reading x. */
 int32_t gts_spmm_max_fwd_f32(const int32_t* indptr, const int32_t* indices, const float* x,
-                             float* out, void* arg, int32_t arg_bytes, int64_t n_dst,
-                             int64_t n_feat, void* stream);
+                             float* out, void* arg, int32_t arg_bytes, int32_t relu_input,
+                             int64_t n_dst, int64_t n_feat, void* stream);
 
 /* ---- K2: max reducer (backward), gather form over the out-CSR -----------------------
  * Replaces the autograd of K1 (DGL scatters gout by argmax).

@@ -123,6 +123,26 @@ def test_sum_family_forward_backward_bit_exact(mode, f):
     assert torch.equal(xd.grad.cpu(), xr.grad), "backward differs"
 
 
+@pytest.mark.parametrize("f", [4, 64, 256])
+def test_relu_input_winner_record_equals_relu_mask_in_the_backward(f):
+    """K1 with relu_input drops the winners whose maximum is not positive; the backward on that
+    record equals the backward on the plain record followed by the ReLU' mask of the source
+    (bit for bit), and the forward values are untouched."""
+    src, dst = random_coo(900, 5000, seed=f)
+    g = gts.Graph(src, dst, 900).to(DEV)
+    p = torch.relu(torch.randn(900, f, device=DEV))             # about half the entries are exactly 0
+    p[17] = 0                                                   # a whole row without any positive value
+    gout = torch.randn(900, f, device=DEV)
+    out_plain, arg_plain = ops.spmm_max_fwd(g, p)
+    out_relu, arg_relu = ops.spmm_max_fwd(g, p, relu_input=True)
+    assert torch.equal(out_plain, out_relu)
+    none = 0xFF if arg_plain.dtype == torch.uint8 else -1
+    changed = arg_plain != arg_relu
+    assert changed.any() and torch.all(arg_relu[changed] == none) and torch.all(out_plain[changed] == 0)
+    want = ops.spmm_max_bwd(g, gout, arg_plain, relu_src=p)
+    assert torch.equal(ops.spmm_max_bwd(g, gout, arg_relu), want)
+
+
 def test_sum_order_sensitivity_case():
     src = np.array([0, 1, 2]); dst = np.array([3, 3, 3])
     _, g = ref_and_gts(src, dst, 4)
