@@ -47,10 +47,6 @@ struct GemmArgs {
   const float* bias;    // [rb] or null
   int relu;
   const float* mask;    // [ra, rb] or null: output zeroed where mask <= 0 (fused ReLU backward)
-  // the same mask as one bit per element, [ra, rb / 32] words (bit c % 32 of word c / 32 of a row;
-  // rb % 32 == 0): written by a forward launch (bit = output > 0), read by an input-gradient one
-  uint32_t* bits_out;
-  const uint32_t* bits_in;
   // split-reduction (weight gradient) only
   const float* pa[kMaxProblems];  // per-problem operands (same shapes)
   const float* pb[kMaxProblems];
@@ -171,27 +167,7 @@ __device__ __forceinline__ void write_tile(const GemmArgs& p, float* lds, float*
 #pragma unroll
               for (int e = 0; e < 4; ++e) val[e] = mk[e] > 0.f ? val[e] : 0.f;
             }
-            if (p.bits_in != nullptr) {  // the 8 lanes of this row segment share one word
-              const uint32_t word = p.bits_in[static_cast<size_t>(row) * (p.rb >> 5) + (col >> 5)];
-              const uint32_t nib = word >> (c4 & 31);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) val[e] = (nib >> e) & 1u ? val[e] : 0.f;
-            }
             *reinterpret_cast<v4f*>(c + off) = val;
-          }
-          if (p.bits_out != nullptr) {
-            // one word per 32-column row segment: the 8 lanes that hold it are neighbours
-            uint32_t nib = 0;
-            if (row < p.ra && col_ok) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) nib |= (val[e] > 0.f ? 1u : 0u) << e;
-            }
-            uint32_t word = nib << (c4 & 31);
-            word |= __shfl_xor(word, 1, kWave);
-            word |= __shfl_xor(word, 2, kWave);
-            word |= __shfl_xor(word, 4, kWave);
-            if ((lane & 7) == 0 && row < p.ra && col_ok)
-              p.bits_out[static_cast<size_t>(row) * (p.rb >> 5) + (col >> 5)] = word;
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -661,16 +637,14 @@ extern "C" int32_t gts_set_option(int32_t option, int32_t value) {
 extern "C" int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const float* a1,
                                       const float* w1, const float* bias, float* out, int64_t m,
                                       int64_t n, int64_t k0, int64_t k1, int32_t relu,
-                                      uint32_t* relu_bits, void* stream) {
+                                      void* stream) {
   using namespace gts;
   if (!a0 || !w0 || !out || ((a1 == nullptr) != (w1 == nullptr))) return GTS_ERR_NULL;
   if (m < 0 || n <= 0 || k0 <= 0 || k1 < 0 || m >= (1LL << 31) || n >= (1 << 20) ||
       k0 >= (1 << 20) || k1 >= (1 << 20) || !aligned4(k0) || !aligned4(k1) || (a1 && k1 == 0))
     return GTS_ERR_SHAPE;
-  if (relu_bits && (!relu || (n & 31) != 0)) return GTS_ERR_ARGKIND;   // bits of a ReLU output, whole words
   if (m == 0) return GTS_OK;
   GemmArgs p{};
-  p.bits_out = relu_bits;
   p.a[0] = a0, p.b[0] = w0, p.lda[0] = static_cast<int>(k0), p.ldb[0] = static_cast<int>(k0);
   p.kseg[0] = static_cast<int>(k0);
   p.a[1] = a1 ? a1 : a0, p.b[1] = w1 ? w1 : w0;
@@ -682,8 +656,7 @@ extern "C" int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const fl
 }
 
 extern "C" int32_t gts_linear_bwd_input_f32(const float* g0, const float* w0, const float* g1,
-                                            const float* w1, const float* relu_mask,
-                                            const uint32_t* relu_mask_bits, float* gin,
+                                            const float* w1, const float* relu_mask, float* gin,
                                             int64_t m, int64_t k, int64_t n0, int64_t n1,
                                             void* stream) {
   using namespace gts;
@@ -701,9 +674,7 @@ extern "C" int32_t gts_linear_bwd_input_f32(const float* g0, const float* w0, co
   p.lda[1] = static_cast<int>(n1), p.ldb[1] = static_cast<int>(k);
   p.kseg[1] = g1 ? static_cast<int>(n1) : 0;
   p.ra = static_cast<int>(m), p.rb = static_cast<int>(k), p.c = gin, p.ldc = static_cast<int>(k);
-  if (relu_mask_bits && (k & 31) != 0) return GTS_ERR_ARGKIND;
   p.mask = relu_mask;
-  p.bits_in = relu_mask_bits;
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
   return launch_plain<true, false>(p, static_cast<hipStream_t>(stream));
 }

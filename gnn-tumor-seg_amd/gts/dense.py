@@ -61,10 +61,8 @@ def _chk(*tensors):
     return require_device(*tensors)
 
 
-def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False, want_relu_bits=False):
-    """out = act(a0 @ w0^T [+ a1 @ w1^T] + bias).  a [M,K], w [N,K] (torch Linear layout).
-    want_relu_bits (with relu, N % 32 == 0): returns (out, bits [M, N/32] int32), bit c%32 of word
-    c/32 = out[r, c] > 0 — the ReLU backward mask for linear_bwd_input(relu_mask_bits=...)."""
+def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False):
+    """out = act(a0 @ w0^T [+ a1 @ w1^T] + bias).  a [M,K], w [N,K] (torch Linear layout)."""
     _same(_mat(a0, "a0").shape[1], _mat(w0, "w0").shape[1], "inner dims of a0 @ w0^T")
     if (a1 is None) != (w1 is None):
         raise _lib.GtsError("a1 and w1 go together")
@@ -79,16 +77,13 @@ def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False, want_relu_bits=F
         a1, w1 = _pad4_cols(a1), _pad4_cols(w1)
     dev = _chk(a0, w0, a1, w1, bias)
     m, n = a0.shape[0], w0.shape[0]
-    if want_relu_bits and (not relu or n % 32 != 0):
-        raise _lib.GtsError("relu bits need relu=True and an output width that is a multiple of 32")
     out = torch.empty((m, n), dtype=torch.float32, device=dev)
-    bits = torch.empty((m, n // 32), dtype=torch.int32, device=dev) if want_relu_bits else None
     k0, k1 = a0.shape[1], a1.shape[1] if a1 is not None else 0
     bias = bias.contiguous() if bias is not None else None
 
     def launch():
         check(_lib.load().gts_linear_fwd_f32(ptr(a0), ptr(w0), ptr(a1), ptr(w1), ptr(bias), ptr(out),
-                                             m, n, k0, k1, 1 if relu else 0, ptr(bits), current_stream()),
+                                             m, n, k0, k1, 1 if relu else 0, current_stream()),
               "gts_linear_fwd_f32")
 
     timer = GEMM_TIMERS.get((n, k0, k1))
@@ -96,12 +91,11 @@ def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False, want_relu_bits=F
         timer(launch)
     else:
         launch()
-    return (out, bits) if want_relu_bits else out
+    return out
 
 
-def linear_bwd_input(g0, w0, g1=None, w1=None, relu_mask=None, relu_mask_bits=None):
-    """g0 @ w0 [+ g1 @ w1].  g [M,N], w [N,K] -> [M,K]; zeroed where relu_mask [M,K] <= 0 or where
-    the bit of relu_mask_bits [M, K/32] (from linear_fwd(want_relu_bits=True)) is clear."""
+def linear_bwd_input(g0, w0, g1=None, w1=None, relu_mask=None):
+    """g0 @ w0 [+ g1 @ w1].  g [M,N], w [N,K] -> [M,K]; zeroed where relu_mask [M,K] <= 0."""
     _same(_mat(g0, "g0").shape[1], _mat(w0, "w0").shape[0], "inner dims of g0 @ w0")
     if (g1 is None) != (w1 is None):
         raise _lib.GtsError("g1 and w1 go together")
@@ -112,10 +106,6 @@ def linear_bwd_input(g0, w0, g1=None, w1=None, relu_mask=None, relu_mask_bits=No
     if relu_mask is not None:
         _same(tuple(relu_mask.shape), (g0.shape[0], w0.shape[1]), "relu_mask vs result")
     k = w0.shape[1]
-    if relu_mask_bits is not None:
-        if k % 32 != 0 or relu_mask_bits.dtype != torch.int32:
-            raise _lib.GtsError("relu_mask_bits: int32 words, result width a multiple of 32")
-        _same(tuple(relu_mask_bits.shape), (g0.shape[0], k // 32), "relu_mask_bits vs result")
     kp = k + (-k) % 4
     g0, w0 = _pad4_cols(g0), _pad4_cols(_pad4_rows(w0))
     if g1 is not None:
@@ -123,13 +113,11 @@ def linear_bwd_input(g0, w0, g1=None, w1=None, relu_mask=None, relu_mask_bits=No
     if relu_mask is not None:
         relu_mask = _pad4_cols(relu_mask)
     dev = _chk(g0, w0, g1, w1, relu_mask)
-    require_device(relu_mask_bits)
     m = g0.shape[0]
     gin = torch.empty((m, kp), dtype=torch.float32, device=dev)
-    check(_lib.load().gts_linear_bwd_input_f32(ptr(g0), ptr(w0), ptr(g1), ptr(w1), ptr(relu_mask),
-                                               ptr(relu_mask_bits), ptr(gin), m, kp, g0.shape[1],
-                                               g1.shape[1] if g1 is not None else 0, current_stream()),
-          "gts_linear_bwd_input_f32")
+    check(_lib.load().gts_linear_bwd_input_f32(ptr(g0), ptr(w0), ptr(g1), ptr(w1), ptr(relu_mask), ptr(gin),
+                                               m, kp, g0.shape[1], g1.shape[1] if g1 is not None else 0,
+                                               current_stream()), "gts_linear_bwd_input_f32")
     return gin if kp == k else gin[:, :k].contiguous()
 
 

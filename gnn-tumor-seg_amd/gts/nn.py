@@ -104,14 +104,8 @@ class _SagePoolStack(torch.autograd.Function):
             last = i == n_layers - 1
             p = dense.linear_fwd(h, w_pool, bias=b_pool, relu=True)
             m, arg = ops.spmm_max_fwd(g, p, want_arg=need_bwd, relu_input=True)   # p is not kept
-            # the hidden layers' ReLU backward mask leaves the forward GEMM as one bit per element
-            # (1/32 of the bytes the input-gradient epilogue would otherwise read back as fp32)
-            bits = None
-            if need_bwd and not last and w_self.shape[0] % 32 == 0:
-                out, bits = dense.linear_fwd(h, w_self, m, w_neigh, bias=bias, relu=True, want_relu_bits=True)
-            else:
-                out = dense.linear_fwd(h, w_self, m, w_neigh, bias=bias, relu=not last)
-            saved += [h, m, arg, bits]
+            out = dense.linear_fwd(h, w_self, m, w_neigh, bias=bias, relu=not last)
+            saved += [h, m, arg]
             h = out
         if need_bwd:
             ctx.g, ctx.n_layers = g, n_layers
@@ -122,7 +116,7 @@ class _SagePoolStack(torch.autograd.Function):
     def backward(ctx, gout):
         n = ctx.n_layers
         tensors = ctx.saved_tensors
-        acts, params = tensors[:4 * n], tensors[4 * n:]
+        acts, params = tensors[:3 * n], tensors[3 * n:]
         grads = [None] * (5 * n)
         g = gout.contiguous()            # gradient w.r.t. the pre-activation output of layer i
         gx = None
@@ -142,7 +136,7 @@ class _SagePoolStack(torch.autograd.Function):
             deferred.setdefault(key, []).append((grad_out, act, bias_slot is not None, slot, bias_slot))
 
         for i in reversed(range(n)):
-            h, m, arg, _bits = acts[4 * i:4 * i + 4]
+            h, m, arg = acts[3 * i:3 * i + 3]
             w_pool, _b_pool, w_self, w_neigh, _bias = params[5 * i:5 * i + 5]
             gm = dense.linear_bwd_input(g, w_neigh)
             gp = ops.spmm_max_bwd(ctx.g, gm, arg)       # ReLU'(p) is already in the winner record
@@ -159,11 +153,7 @@ class _SagePoolStack(torch.autograd.Function):
                 keep_alive.append((g, gp))              # still being read by the side stream
                 grads[5 * i:5 * i + 5] = [g_wp, g_bp, g_ws, g_wn, g_bias]
             if i > 0:      # h is layer i-1's ReLU output: its backward is the mask h > 0
-                prev_bits = acts[4 * (i - 1) + 3]
-                if prev_bits is not None:
-                    g = dense.linear_bwd_input(g, w_self, gp, w_pool, relu_mask_bits=prev_bits)
-                else:
-                    g = dense.linear_bwd_input(g, w_self, gp, w_pool, relu_mask=h)
+                g = dense.linear_bwd_input(g, w_self, gp, w_pool, relu_mask=h)
             elif ctx.needs_input_grad[1]:
                 gx = dense.linear_bwd_input(g, w_self, gp, w_pool)
         for problems in deferred.values():

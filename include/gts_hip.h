@@ -201,20 +201,16 @@ int32_t gts_label_confusion_i16(const int16_t* pred, const int16_t* truth, int64
  *
  * forward:  out[m, n] = act( sum_k a0[m,k] w0[n,k] + (a1 ? sum_k a1[m,k] w1[n,k] : 0) + bias[n] )
  *   a0 [M,K0], w0 [N,K0], a1 [M,K1], w1 [N,K1] row-major (torch Linear layout); bias optional;
- *   relu != 0 applies max(., 0).  The pair form is fc_self(h) + fc_neigh(m) in one pass.
- *   relu_bits (optional; needs relu != 0 and n % 32 == 0): [m, n / 32] words, bit c % 32 of word
- *   c / 32 of row r = (out[r, c] > 0) — the ReLU backward mask in 1/32 of the bytes. */
+ *   relu != 0 applies max(., 0).  The pair form is fc_self(h) + fc_neigh(m) in one pass. */
 int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const float* a1, const float* w1,
                            const float* bias, float* out, int64_t m, int64_t n, int64_t k0,
-                           int64_t k1, int32_t relu, uint32_t* relu_bits, void* stream);
+                           int64_t k1, int32_t relu, void* stream);
 /* input gradient:  gin[m, k] = sum_n g0[m,n] w0[n,k] + (g1 ? sum_n g1[m,n] w1[n,k] : 0)
- *   g0 [M,N0], w0 [N0,K], g1 [M,N1], w1 [N1,K].  The ReLU backward of the layer that produced
- *   this input is fused into the epilogue: gin is zeroed where relu_mask [M,K] <= 0 (optional)
- *   and/or where the bit of relu_mask_bits [M, K/32] (optional, k % 32 == 0; the relu_bits a
- *   forward call wrote) is clear. */
+ *   g0 [M,N0], w0 [N0,K], g1 [M,N1], w1 [N1,K].  relu_mask (optional, [M,K]): gin is zeroed
+ *   where relu_mask <= 0, i.e. the ReLU backward of the layer that produced this input. */
 int32_t gts_linear_bwd_input_f32(const float* g0, const float* w0, const float* g1, const float* w1,
-                                 const float* relu_mask, const uint32_t* relu_mask_bits, float* gin,
-                                 int64_t m, int64_t k, int64_t n0, int64_t n1, void* stream);
+                                 const float* relu_mask, float* gin, int64_t m, int64_t k,
+                                 int64_t n0, int64_t n1, void* stream);
 /* weight gradients of n_problems (1..32) same-shape problems in ONE launch (the three weight
  * gradients of a SAGE layer, or those of a whole stack of equal layers):  gw[q][n, k] = sum_m g[q][m,n] a[q][m,k];
  * gb[q][n] = sum_m g[q][m,n] where gb && gb[q].  g, a, gw, gb are HOST arrays of device pointers.

@@ -130,24 +130,6 @@ def test_many_weight_gradients_in_one_launch(m, n, k, count):
     assert all(torch.equal(x[0], y[0]) for x, y in zip(out, again))      # fixed-order slabs: reproducible
 
 
-@pytest.mark.parametrize("m,n,k", [(1000, 256, 64), (60000, 256, 256), (333, 64, 32), (50001, 1024, 128)])
-def test_relu_bit_mask_round_trip(m, n, k):
-    """The forward GEMM's optional 1-bit-per-element ReLU mask: bit (r, c) == out[r, c] > 0, and an
-    input gradient masked with the bits equals the one masked with the fp32 output, bit for bit."""
-    a, w, b = _rand(m, k, seed=1).to(DEV), _rand(n, k, seed=2).to(DEV), _rand(n, seed=3).to(DEV)
-    plain = dense.linear_fwd(a, w, bias=b, relu=True)
-    out, bits = dense.linear_fwd(a, w, bias=b, relu=True, want_relu_bits=True)
-    assert torch.equal(out, plain) and bits.shape == (m, n // 32) and bits.dtype == torch.int32
-    unpacked = (bits.unsqueeze(-1) >> torch.arange(32, device=DEV)) & 1
-    assert torch.equal(unpacked.reshape(m, n).bool(), out > 0)
-    g, w2 = _rand(m, 96, seed=4).to(DEV), _rand(96, n, seed=5).to(DEV)
-    assert torch.equal(dense.linear_bwd_input(g, w2, relu_mask_bits=bits), dense.linear_bwd_input(g, w2, relu_mask=out))
-    with pytest.raises(Exception):
-        dense.linear_fwd(a, w, bias=b, relu=False, want_relu_bits=True)
-    with pytest.raises(Exception):
-        dense.linear_bwd_input(g, w2, relu_mask_bits=bits[:, :-1])
-
-
 def test_linear_autograd_matches_torch():
     x = _rand(333, 20, seed=1).to(DEV).requires_grad_(True)
     w = _rand(64, 20, seed=2).to(DEV).requires_grad_(True)

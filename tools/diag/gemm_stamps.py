@@ -19,7 +19,7 @@ subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offl
                        "-DGTS_GEMM_STAMPS", f"-I{REPO}/include", f"-I{REPO}/gnn-tumor-seg_amd/csrc", "-o", so, *src])
 lib = ctypes.CDLL(so)
 p, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
-lib.gts_linear_fwd_f32.argtypes = [p, p, p, p, p, p, i64, i64, i64, i64, i32, p, p]
+lib.gts_linear_fwd_f32.argtypes = [p, p, p, p, p, p, i64, i64, i64, i64, i32, p]
 lib.gts_diag_set_stamps.argtypes = [p]
 lib.gts_diag_set_flags.argtypes = [i32]
 lib.gts_set_option.argtypes = [i32, i32]
@@ -38,7 +38,7 @@ for variant, bm, bn in ((3, 64, 256), (1, 128, 256), (8, 256, 256)):
             lib.gts_diag_set_stamps(stamps.data_ptr())
             lib.gts_linear_fwd_f32(x.data_ptr(), w.data_ptr(), y.data_ptr() if dual else None,
                                    w2.data_ptr() if dual else None, b.data_ptr(), out.data_ptr(), M, F, F,
-                                   F if dual else 0, 1, None, st)
+                                   F if dual else 0, 1, st)
             torch.cuda.synchronize()
         t = stamps.cpu().numpy().reshape(n_blocks, 4).astype(np.float64) * 0.01   # 100 MHz -> us
         t0 = t[:, 0].min()
@@ -59,7 +59,7 @@ for variant in (1, 8):
         lib.gts_diag_set_flags(flags)
         for dual in (False, True):
             args = (x.data_ptr(), w.data_ptr(), y.data_ptr() if dual else None, w2.data_ptr() if dual else None,
-                    b.data_ptr(), out.data_ptr(), M, F, F, F if dual else 0, 1, None, st)
+                    b.data_ptr(), out.data_ptr(), M, F, F, F if dual else 0, 1, st)
             for _ in range(3):
                 lib.gts_linear_fwd_f32(*args)
             torch.cuda.synchronize()
