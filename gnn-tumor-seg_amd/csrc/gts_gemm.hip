@@ -148,6 +148,17 @@ __device__ __forceinline__ void write_tile(const GemmArgs& p, float* lds, float*
       if (p.bias != nullptr && col_ok) bias = *reinterpret_cast<const v4f*>(p.bias + col);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
+        // the ReLU mask of this tile is requested first: its latency hides behind the LDS staging
+        v4f mk[4];
+        if (p.mask != nullptr) {
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int row = m0 + wm * WTM + tm * 32 + it * 8 + srow;
+            mk[it] = (row < p.ra && col_ok)
+                         ? *reinterpret_cast<const v4f*>(p.mask + static_cast<size_t>(row) * p.ldc + col)
+                         : v4f{0.f, 0.f, 0.f, 0.f};
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * kKcLd + i] = acc[tm][tn][r];
         __builtin_amdgcn_wave_barrier();
@@ -163,9 +174,8 @@ __device__ __forceinline__ void write_tile(const GemmArgs& p, float* lds, float*
               for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
             }
             if (p.mask != nullptr) {
-              const v4f mk = *reinterpret_cast<const v4f*>(p.mask + off);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) val[e] = mk[e] > 0.f ? val[e] : 0.f;
+              for (int e = 0; e < 4; ++e) val[e] = mk[it][e] > 0.f ? val[e] : 0.f;
             }
             *reinterpret_cast<v4f*>(c + off) = val;
           }
