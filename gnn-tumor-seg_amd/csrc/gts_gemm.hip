@@ -387,6 +387,7 @@ __global__ __launch_bounds__(kBlock) void reduce_slabs_kernel(const ReduceArgs p
   v4f acc = {0.f, 0.f, 0.f, 0.f};
   if (i < n4) {
     const v4f* src = reinterpret_cast<const v4f*>(slabs) + i;
+#pragma unroll 8   // independent loads, issued back to back (the adds keep their order)
     for (int s = grp; s < p.splits; s += 4) acc += src[static_cast<size_t>(s) * n4];
   }
   part[grp][col] = acc;
