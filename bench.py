@@ -2,7 +2,7 @@
 """Headline benchmark: training throughput (supervoxel-graphs/sec) of 7xGraphSAGE-pool-256
 on synthetic 15k-node supervoxel graphs, N MI355X GPUs (BASELINE.json metric, config C2).
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus N --steps 20 --warmup 5          (N > 1: starts its own torchrun child)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -12,12 +12,23 @@ graphs per GPU (N_b = 60 000 nodes, E_b = 345 400 edges), in_feats 4, fp32, laye
 [256]*7 => 8 SAGEConv layers.  Inputs are resident in HBM before the timed region.  Weak
 scaling: per-GPU work is fixed, global batch = graphs-per-gpu x N.
 
+Timing: after W warm-up steps the block of EXACTLY K steps (barrier + synchronize on both
+sides, MAX over ranks) is timed `--blocks` times (default 10); `value` is the MEDIAN block's
+rate and `blocks` carries min / median / max.  One further block of the same K steps runs
+with HIP events around every launch of the kernels the roofline objects describe.
+
 Rank 0 prints ONE JSON line with the throughput, plus
-  "roofline":     achieved algorithmic bandwidth of the dominant aggregation kernel
-                  (spmm_max_fwd, F=256, with argmax) from HIP events around every launch of
-                  it inside the timed region, against the 8 TB/s HBM peak;
+  "roofline":     K11, the MFMA fp32 GEMM kernel most of the step is spent in: flops of every
+                  forward / input-gradient / weight-gradient launch / their summed HIP-event
+                  durations, against the 157.3 TFLOP/s dense fp32 MFMA peak;
+  "roofline_hbm": the HBM-bound kernels of the path (K1 spmm_max_fwd, K2 spmm_max_bwd at
+                  F=256; gat_fwd; project_rows): COMPULSORY bytes (each input/output array
+                  once) / mean launch duration against the 8 TB/s HBM peak, with the per-edge
+                  `algorithmic_*` figure of SURVEY §8d and the PMC traffic of the committed
+                  profile (tagged with its source file) beside it;
   "cpu_baseline": the CPU oracle (pure-PyTorch restatement of the DGL CPU path) timed on this
-                  box's host cores on a bounded sample of the same workload (N=1 only).
+                  box's host cores on a bounded sample of the same workload (N=1 only);
+  "ranks", "backend", "all_reduce": what the collective saw when N > 1.
 
 Other BASELINE.json configurations (parity-test cases, not the headline) can be timed with
   --config c3   GAT 4 layers x 4 heads x 256 training on the same graphs   (graphs/s)
@@ -50,13 +61,13 @@ CLASS_WEIGHTS = [0.1, 1.0, 2.0, 2.0]
 CONFIGS = {
     "c2": dict(model="GSpool", layer_sizes=[256] * 7, heads=None, residuals=None,
                metric="supervoxel-graphs/sec training, 7xSAGE-pool-256, 15k-node graphs",
-               kernel="spmm_max_fwd_f256"),
+               hbm_kernels=("spmm_max_fwd_f256", "spmm_max_bwd_f256")),
     "c3": dict(model="GAT", layer_sizes=[256] * 4, heads=[4] * 4, residuals=[False] * 4,
                metric="supervoxel-graphs/sec training, GAT 4 layers x 4 heads x 256, 15k-node graphs",
-               kernel="gat_fwd"),
+               hbm_kernels=("gat_fwd",)),
     "c5": dict(model="GSpool", layer_sizes=[256] * 7, heads=None, residuals=None,
                metric="volumes/sec inference: 7xSAGE-pool-256 forward + node-logit->voxel projection to 240^3",
-               kernel="project_rows"),
+               hbm_kernels=("project_rows",)),
 }
 
 
@@ -65,6 +76,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--blocks", type=int, default=10,
+                    help="the --steps block is timed this many times; value = the median block")
     ap.add_argument("--graphs-per-gpu", type=int, default=4)
     ap.add_argument("--graph-kind", default="lattice", choices=["lattice", "random"])
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
@@ -77,28 +90,33 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-class KernelTimer:
-    """HIP-event pairs around every launch of one kernel on torch's current stream (the
-    stream gts launches on)."""
+class KernelTimers:
+    """HIP-event pairs around kernel launches on torch's current stream (the stream gts launches
+    on), grouped by name; `work` = flops (or anything additive) the caller attaches to a launch."""
 
-    def __init__(self, max_pairs=None):
-        self.pairs = []
+    def __init__(self):
+        self.pairs = {}
         self.enabled = False
-        self.max_pairs = max_pairs      # sample only the first launches (keeps the event cost off the step)
 
-    def __call__(self, launch):
-        if not self.enabled or (self.max_pairs is not None and len(self.pairs) >= self.max_pairs):
-            return launch()
-        a = torch.cuda.Event(enable_timing=True)
-        b = torch.cuda.Event(enable_timing=True)
-        a.record()
-        out = launch()
-        b.record()
-        self.pairs.append((a, b))
-        return out
+    def bracket(self, name, work=0.0):
+        def run(launch):
+            if not self.enabled:
+                return launch()
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = launch()
+            b.record()
+            self.pairs.setdefault(name, []).append((a, b, work))
+            return out
+        return run
 
-    def mean_ms(self):
-        return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else None
+    def summary(self, name):
+        pairs = self.pairs.get(name)
+        if not pairs:
+            return None
+        return {"launches": len(pairs), "total_ms": float(sum(a.elapsed_time(b) for a, b, _ in pairs)),
+                "work": float(sum(w for _, _, w in pairs))}
 
 
 def build_batches(rank, graphs_per_gpu, kind, n_batches, device):
@@ -168,10 +186,14 @@ def cpu_baseline(cfg, graphs_per_gpu, kind, steps):
 
 
 def algorithmic_bytes(kernel, n_b, e_b, arg_bytes, heads=4, dim=256, n_vox=240 ** 3):
-    """Bytes one launch of the dominant kernel must move."""
+    """Per-edge traffic model of one launch: every edge fetches its source row.
+    Most of those re-reads are served by the XCD's L2, so this is NOT what HBM sees; it is kept
+    as `algorithmic_*` beside the compulsory figure the roofline fraction is computed from."""
     f = 256
     if kernel == "spmm_max_fwd_f256":   # source row per edge + out row + argmax slots + int32 CSR
         return 4 * f * e_b + 4 * f * n_b + arg_bytes * f * n_b + 4 * (e_b + n_b + 1)
+    if kernel == "spmm_max_bwd_f256":   # gout row + winner slots per out-edge, gx row, out-CSR + t_slot
+        return (4 * f + arg_bytes * f) * e_b + 4 * f * n_b + 4 * (2 * e_b + n_b + 1)
     if kernel == "gat_fwd":             # ft slice per (edge, head) + out + attn + el/er + CSR
         return 4 * heads * dim * e_b + 4 * heads * dim * n_b + 4 * heads * (3 * e_b + 2 * n_b) + 4 * (e_b + n_b + 1)
     if kernel == "project_rows":        # int16 id in, 16-byte row out, per voxel
@@ -179,14 +201,46 @@ def algorithmic_bytes(kernel, n_b, e_b, arg_bytes, heads=4, dim=256, n_vox=240 *
     raise ValueError(kernel)
 
 
+def compulsory_bytes(kernel, n_b, e_b, arg_bytes, heads=4, dim=256, n_vox=240 ** 3):
+    """Bytes one launch cannot avoid moving across HBM: every input and output array once."""
+    f = 256
+    if kernel == "spmm_max_fwd_f256":   # x in, out, argmax slots, in-CSR
+        return 4 * f * n_b + 4 * f * n_b + arg_bytes * f * n_b + 4 * (e_b + n_b + 1)
+    if kernel == "spmm_max_bwd_f256":   # gout in, winner slots in, gx out, out-CSR + t_slot
+        return 4 * f * n_b + arg_bytes * f * n_b + 4 * f * n_b + 4 * (2 * e_b + n_b + 1)
+    if kernel == "gat_fwd":             # ft in, out, attn out, el/er in, bias, in-CSR
+        return (2 * 4 * heads * dim * n_b + 4 * heads * e_b + 2 * 4 * heads * n_b + 4 * heads * dim
+                + 4 * (e_b + n_b + 1))
+    if kernel == "project_rows":        # ids in, rows out, the node table once
+        return (2 + 16) * n_vox + 16 * n_b
+    raise ValueError(kernel)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the ranks as a CHILD process
+    (one per GPU, RCCL) before this process has made any GPU call, and leave with its code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log("not under torchrun: " + " ".join(cmd))
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+
+
 def main():
     args = parse_args()
     cfg = CONFIGS[args.config]
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))          # nothing above touched the GPU
     from gts import dist as gdist
 
     rank, world, local_rank = gdist.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs (the HIP path has no CPU fallback)")
     device = torch.device("cuda", torch.cuda.current_device())
@@ -205,13 +259,11 @@ def main():
     batches = build_batches(rank, args.graphs_per_gpu, args.graph_kind, n_batches=2, device=device)
     n_b, e_b = batches[0][0].n, batches[0][0].number_of_edges()
 
-    timer = KernelTimer()
-    ops.KERNEL_TIMERS[cfg["kernel"]] = timer
-    # K11, the kernel most of the step's time is spent in: the hidden layers' forward GEMM
-    # out = h W_self^T + m W_neigh^T + b (C2/C5: N=256, K=256+256; C3: fc, N=1024, K=1024)
-    gemm_shape = (1024, 1024, 0) if args.config == "c3" else (256, 256, 256)
-    gemm_timer = KernelTimer(max_pairs=36)
-    dense.GEMM_TIMERS[gemm_shape] = gemm_timer
+    timers = KernelTimers()
+    for name in cfg["hbm_kernels"]:
+        ops.KERNEL_TIMERS[name] = timers.bracket(name)
+    dense.GEMM_TIMER = lambda kind, flops, launch: timers.bracket("gemm_" + kind, flops)(launch)
+    gdist.COLLECTIVE_TIMER = timers.bracket("all_reduce")
 
     if args.config == "c5":
         model.net.eval()
@@ -238,50 +290,58 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def timed_block():
+        """EXACTLY --steps steps between two fences; (seconds [max over ranks], host enqueue s, last)."""
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            last = step(i)
+        enqueue = time.perf_counter() - t0      # CPU time to enqueue K steps (no sync inside)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, enqueue, last
+
     log(f"rank {rank}/{world}: {args.config} batches resident (N_b={n_b}, E_b={e_b}); warm-up")
     for i in range(args.warmup):
         step(i)
-    fence()
-    log("timed region")
-    timer.enabled = gemm_timer.enabled = True
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        last = step(i)
-    host_enqueue = time.perf_counter() - t0     # CPU time to enqueue K steps (no sync inside)
-    fence()
-    elapsed = time.perf_counter() - t0
-    timer.enabled = gemm_timer.enabled = False
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    log(f"timed region done: {elapsed:.3f} s for {args.steps} steps "
-        f"(host enqueue {1e3 * host_enqueue / args.steps:.2f} ms/step)")
+    log(f"timed region: {args.blocks} blocks of {args.steps} steps")
+    blocks = [timed_block() for _ in range(args.blocks)]
+    times = sorted(b[0] for b in blocks)
+    elapsed = float(np.median(times))            # the headline: median block
+    host_enqueue = float(np.median([b[1] for b in blocks]))
+    last = blocks[-1][2]
+    # one more block of the same K steps with HIP events around every launch of the kernels the
+    # roofline objects describe (kept out of the blocks above: events cost a few us per launch)
+    timers.enabled = True
+    instrumented = timed_block()[0]
+    timers.enabled = False
+    log(f"blocks: median {elapsed:.4f} s, min {times[0]:.4f}, max {times[-1]:.4f} for {args.steps} steps; "
+        f"instrumented block {instrumented:.4f} s (host enqueue {1e3 * host_enqueue / args.steps:.2f} ms/step)")
     global_batch = args.graphs_per_gpu * world
     value = global_batch * args.steps / elapsed
 
     if rank == 0:
-        alg_bytes = algorithmic_bytes(cfg["kernel"], n_b, e_b, batches[0][0].arg_bytes)
-        ms = timer.mean_ms()
-        achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms else None
-        traffic = None
-        # the committed PMC / rocprof figures were taken on the default workload only
-        profiled = args.graphs_per_gpu == 4 and args.graph_kind == "lattice"
-        pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if profiled and os.path.exists(pmc_path):
-            with open(pmc_path) as fh:
-                traffic = json.load(fh).get(cfg["kernel"] + "_bytes_per_launch")
-        rocprof_us = None     # kernel-only duration from the committed rocprofv3 summary, for comparison:
-        avg_path = os.path.join(REPO, "profiles", "rocprof_kernel_avg.json")   # event brackets add the
-        if profiled and os.path.exists(avg_path):                                # two kernel boundaries
-            with open(avg_path) as fh:
-                rocprof_us = json.load(fh).get(cfg["kernel"] + "_avg_us")
+        arg_b = batches[0][0].arg_bytes
+        profiled = args.graphs_per_gpu == 4 and args.graph_kind == "lattice"   # what the committed profiles ran
+
+        def from_profile(fname, key):
+            path = os.path.join(REPO, "profiles", fname)
+            if not (profiled and os.path.exists(path)):
+                return None, None
+            with open(path) as fh:
+                return json.load(fh).get(key), "profiles/" + fname
+
         workloads = {
             "c2": "C2: 7xGraphSAGE-pool-256 (8 SAGEConv), fwd+weighted-CE+bwd+AdamW",
             "c3": "C3: GAT 4 layers x 4 heads x 256 (5 GATConv), fwd+weighted-CE+bwd+AdamW",
             "c5": "C5: no-grad forward of 7xGraphSAGE-pool-256 + logits projection of every graph to an "
                   "int16 240^3 partition (fp32 x4 rows)",
         }
+        rate = lambda t: global_batch * args.steps / t          # noqa: E731
         result = {
             "metric": cfg["metric"], "value": round(value, 3),
             "unit": "volumes/s" if args.config == "c5" else "graphs/s", "n_gpus": world,
@@ -294,24 +354,60 @@ def main():
                        "global_batch": global_batch, "nodes_per_batch": n_b, "edges_per_batch": e_b,
                        "parallelism": f"dp{world}", "last_value": round(float(last), 6),
                        "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3)},
-            "roofline": {"bound": "hbm", "kernel": cfg["kernel"],
-                         "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_us": round(ms * 1e3, 2) if ms else None,
-                         "rocprof_avg_launch_us": rocprof_us,
-                         "launches_timed": len(timer.pairs)},
+            "blocks": {"n": args.blocks, "steps_per_block": args.steps, "value": "median block",
+                       "median": round(rate(elapsed), 3), "min": round(rate(times[-1]), 3),
+                       "max": round(rate(times[0]), 3)},
+            "ranks": world,
+            "backend": torch.distributed.get_backend() if world > 1 else None,
         }
-        gemm_ms = gemm_timer.mean_ms()
-        if gemm_ms:
-            n, k0, k1 = gemm_shape
-            flops = 2.0 * n_b * n * (k0 + k1)
-            tf = flops / (gemm_ms * 1e-3) / 1e12
-            result["roofline_mfma"] = {
-                "bound": "mfma", "kernel": f"linear_fwd [{n_b}x{k0}+{k1}] x [{n}x{k0 + k1}]^T (K11)",
+        # --- K11, where most of the step goes (all three GEMM forms are one kernel template)
+        kinds = {k: timers.summary("gemm_" + k) for k in ("fwd", "igrad", "wgrad")}
+        kinds = {k: v for k, v in kinds.items() if v}
+        sample = f"HIP events around every launch in one extra block of {args.steps} steps after the timed blocks"
+        if kinds:
+            flops = sum(v["work"] for v in kinds.values())
+            secs = sum(v["total_ms"] for v in kinds.values()) * 1e-3
+            tf = flops / secs / 1e12
+            result["roofline"] = {
+                "bound": "mfma", "kernel": "gts::gemm_kernel (K11: every forward / input-gradient / "
+                                           "weight-gradient launch of the step)",
                 "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "flops_per_launch": flops,
-                "avg_launch_us": round(gemm_ms * 1e3, 2), "launches_timed": len(gemm_timer.pairs)}
+                "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "flops_per_step": flops / args.steps, "gemm_ms_per_step": round(1e3 * secs / args.steps, 4),
+                "share_of_step": round(secs / instrumented, 3),
+                "by_kind": {k: {"launches_per_step": v["launches"] / args.steps,
+                                "avg_launch_us": round(1e3 * v["total_ms"] / v["launches"], 2),
+                                "tflops": round(v["work"] / (v["total_ms"] * 1e-3) / 1e12, 1)}
+                            for k, v in kinds.items()},
+                "sample": sample}
+        # --- the HBM-bound kernels of the path: fraction from COMPULSORY bytes (each array once)
+        hbm = []
+        for name in cfg["hbm_kernels"]:
+            s = timers.summary(name)
+            if not s:
+                continue
+            us = 1e3 * s["total_ms"] / s["launches"]
+            need = compulsory_bytes(name, n_b, e_b, arg_b)
+            alg = algorithmic_bytes(name, n_b, e_b, arg_b)
+            traffic, source = from_profile("pmc_traffic.json", name + "_bytes_per_launch")
+            rocprof_us, rsource = from_profile("rocprof_kernel_avg.json", name + "_avg_us")
+            gbs = need / (us * 1e-6) / 1e9
+            hbm.append({"bound": "hbm", "kernel": name, "model": "compulsory bytes: every input/output array once",
+                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "compulsory_bytes_per_launch": need,
+                        "traffic": traffic, "traffic_source": source,
+                        "algorithmic_bytes_per_launch": alg,
+                        "algorithmic_gbs": round(alg / (us * 1e-6) / 1e9, 1),
+                        "avg_launch_us": round(us, 2), "launches_timed": s["launches"],
+                        "rocprof_avg_launch_us": rocprof_us, "rocprof_source": rsource, "sample": sample})
+        result["roofline_hbm"] = hbm
+        if "roofline" not in result and hbm:
+            result["roofline"] = hbm[0]
+        ar = timers.summary("all_reduce")
+        if ar:
+            result["all_reduce"] = {"payload_bytes": int(model.grad_sync.flat.numel() * 4),
+                                    "avg_us": round(1e3 * ar["total_ms"] / ar["launches"], 1),
+                                    "launches_timed": ar["launches"]}
         if world == 1 and not args.no_cpu_baseline and args.config != "c5":
             cpu_steps = 1 if args.config == "c3" else args.cpu_steps   # a GAT step takes ~1 min on the CPU
             result["cpu_baseline"] = cpu_baseline(cfg, args.graphs_per_gpu, args.graph_kind, cpu_steps)

@@ -14,9 +14,13 @@ import torch.nn.functional as F
 from . import _lib
 from ._lib import check, current_stream, ptr, require_device
 
-# bench.py installs callables here ((n, k0, k1) of a forward GEMM -> wrapper) to bracket those
-# launches with HIP events; empty in normal use.
-GEMM_TIMERS = {}
+# bench.py installs a callable here, timer(kind, flops, launch) with kind in {"fwd", "igrad",
+# "wgrad"}, to bracket every K11 launch with HIP events; None in normal use.
+GEMM_TIMER = None
+
+
+def _timed(kind, flops, launch):
+    return GEMM_TIMER(kind, flops, launch) if GEMM_TIMER is not None else launch()
 
 _workspaces = {}
 
@@ -86,11 +90,7 @@ def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False):
                                              m, n, k0, k1, 1 if relu else 0, current_stream()),
               "gts_linear_fwd_f32")
 
-    timer = GEMM_TIMERS.get((n, k0, k1))
-    if timer is not None:
-        timer(launch)
-    else:
-        launch()
+    _timed("fwd", 2.0 * m * n * (k0 + k1), launch)
     return out
 
 
@@ -115,9 +115,10 @@ def linear_bwd_input(g0, w0, g1=None, w1=None, relu_mask=None):
     dev = _chk(g0, w0, g1, w1, relu_mask)
     m = g0.shape[0]
     gin = torch.empty((m, kp), dtype=torch.float32, device=dev)
-    check(_lib.load().gts_linear_bwd_input_f32(ptr(g0), ptr(w0), ptr(g1), ptr(w1), ptr(relu_mask), ptr(gin),
-                                               m, kp, g0.shape[1], g1.shape[1] if g1 is not None else 0,
-                                               current_stream()), "gts_linear_bwd_input_f32")
+    n0, n1 = g0.shape[1], g1.shape[1] if g1 is not None else 0
+    _timed("igrad", 2.0 * m * kp * (n0 + n1), lambda: check(
+        _lib.load().gts_linear_bwd_input_f32(ptr(g0), ptr(w0), ptr(g1), ptr(w1), ptr(relu_mask), ptr(gin),
+                                             m, kp, n0, n1, current_stream()), "gts_linear_bwd_input_f32"))
     return gin if kp == k else gin[:, :k].contiguous()
 
 
@@ -153,10 +154,11 @@ def linear_bwd_weight_multi(problems):
         nbytes = lib.gts_linear_bwd_weight_workspace(m, n_p, k_p, q)
         ws = _workspace(dev, nbytes)
         arr = ctypes.c_void_p * q
-        check(lib.gts_linear_bwd_weight_f32(arr(*[ptr(t) for t in gs]), arr(*[ptr(t) for t in acts]),
-                                            arr(*[ptr(t) for t in gws]), arr(*[ptr(t) for t in gbs]), q,
-                                            ptr(ws), ws.numel() * 4, m, n_p, k_p, current_stream()),
-              "gts_linear_bwd_weight_f32")
+        _timed("wgrad", 2.0 * m * n_p * k_p * q, lambda: check(
+            lib.gts_linear_bwd_weight_f32(arr(*[ptr(t) for t in gs]), arr(*[ptr(t) for t in acts]),
+                                          arr(*[ptr(t) for t in gws]), arr(*[ptr(t) for t in gbs]), q,
+                                          ptr(ws), ws.numel() * 4, m, n_p, k_p, current_stream()),
+            "gts_linear_bwd_weight_f32"))
     out = []
     for gw, gb in zip(gws, gbs):
         if (n_p, k_p) != (n, k):

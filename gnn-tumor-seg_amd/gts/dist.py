@@ -23,6 +23,11 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 
+# bench.py installs a callable here (launch -> result) to bracket the gradient all-reduce with HIP
+# events; None in normal use.
+COLLECTIVE_TIMER = None
+
+
 def world():
     """(rank, world_size) of the default process group, (0, 1) when not initialised."""
     if dist.is_available() and dist.is_initialized():
@@ -116,7 +121,11 @@ class FlatGradSync:
         self._scalars = None
         _, w = world()
         if w > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            reduce = lambda: dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)  # noqa: E731
+            if COLLECTIVE_TIMER is not None:
+                COLLECTIVE_TIMER(reduce)
+            else:
+                reduce()
         den = self.flat[self.n_grad]
         loss = self.flat[self.n_grad + 1] / den
         self.flat[:self.n_grad].div_(den)

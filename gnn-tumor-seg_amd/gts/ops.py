@@ -11,7 +11,8 @@ from ._lib import check, current_stream, ptr, require_device
 _ARG_DTYPE = {0: torch.uint8, 1: torch.uint8, 4: torch.int32}
 
 # bench.py installs callables here (kernel name -> wrapper) to bracket each launch of a kernel
-# with HIP events; empty in normal use.  Names: "spmm_max_fwd_f256", "gat_fwd", "project_rows".
+# with HIP events; empty in normal use.  Names: "spmm_max_fwd_f256", "spmm_max_bwd_f256", "gat_fwd",
+# "project_rows".
 KERNEL_TIMERS = {}
 
 
@@ -72,9 +73,14 @@ def spmm_max_bwd(g, gout, arg, relu_src=None):
     if arg.dtype != _ARG_DTYPE[g.arg_bytes]:
         raise _lib.GtsError(f"arg dtype {arg.dtype} does not belong to this graph ({_ARG_DTYPE[g.arg_bytes]})")
     gx = torch.empty((n, f), dtype=torch.float32, device=gout.device)
-    check(_lib.load().gts_spmm_max_bwd_f32(ptr(d.t_indptr), ptr(d.t_indices), ptr(d.t_slot), ptr(gout),
-                                           ptr(arg), arg.element_size(), ptr(relu_src), ptr(gx), n, f,
-                                           current_stream()), "gts_spmm_max_bwd_f32")
+    lib = _lib.load()
+
+    def launch():
+        return lib.gts_spmm_max_bwd_f32(ptr(d.t_indptr), ptr(d.t_indices), ptr(d.t_slot), ptr(gout),
+                                        ptr(arg), arg.element_size(), ptr(relu_src), ptr(gx), n, f,
+                                        current_stream())
+
+    check(_timed("spmm_max_bwd_f256", launch) if f == 256 else launch(), "gts_spmm_max_bwd_f32")
     return gx
 
 
