@@ -253,8 +253,7 @@ def main():
     with contextlib.redirect_stdout(sys.stderr):   # stdout carries the JSON line only
         model = GNN(cfg["model"], hyperparams(cfg), None)
     if world > 1:
-        for p in model.net.parameters():
-            torch.distributed.broadcast(p.data, src=0)
+        gdist.broadcast_parameters(model.net.parameters(), src=0)
         model.grad_sync = gdist.FlatGradSync(model.net.parameters())
     batches = build_batches(rank, args.graphs_per_gpu, args.graph_kind, n_batches=2, device=device)
     n_b, e_b = batches[0][0].n, batches[0][0].number_of_edges()

@@ -119,7 +119,8 @@ class ImageGraphDataset(torch.utils.data.Dataset):
         return nifti_io.read_nifti(self._path(mri_id, "_supervoxels.nii.gz"), np.int16)
 
     def get_crop(self, mri_id):
-        return tuple(np.load(self._path(mri_id, "_crop.npy"), allow_pickle=True))
+        """np.ix_-shaped index triple of the sample inside the (240, 240, 155) BraTS volume."""
+        return load_crop(self._path(mri_id, "_crop.npy"))
 
     def __iter__(self):
         return (self.get_one(mri_id) for mri_id in self.all_ids)
@@ -129,6 +130,50 @@ class ImageGraphDataset(torch.utils.data.Dataset):
 
     def __len__(self):
         return len(self.all_ids)
+
+
+def save_crop(path_npz, crop):
+    """Write a crop (np.ix_ triple or three index vectors) as three plain int64 arrays."""
+    x, y, z = (np.asarray(a, dtype=np.int64).reshape(-1) for a in crop)
+    np.savez(path_npz, x=x, y=y, z=z)
+
+
+class _ArraysOnlyUnpickler(__import__("pickle").Unpickler):
+    """Unpickler for the reference's `_crop.npy` (np.save of a tuple of three differently shaped
+    index arrays = a pickled object array, scripts/preprocess_dataset.py:130).  It can rebuild
+    numpy arrays / dtypes / scalars and nothing else: any other global in the stream raises."""
+
+    _ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                ("numpy", "ndarray"), ("numpy", "dtype")}
+
+    def find_class(self, module, name):
+        if (module, name) not in self._ALLOWED:
+            raise ValueError(f"crop file asks for {module}.{name}: not an array, refusing to load it")
+        return super().find_class(module, name)
+
+
+def load_crop(path_npy):
+    """Crop of a sample as an np.ix_-shaped triple.  Reads `{id}_crop.npz` (three plain index
+    arrays, `save_crop`) when it exists; otherwise the reference's `{id}_crop.npy`, without ever
+    running numpy's general pickle loader on it."""
+    path_npz = path_npy[:-4] + ".npz"
+    if os.path.exists(path_npz):
+        with np.load(path_npz, allow_pickle=False) as z:
+            return np.ix_(z["x"], z["y"], z["z"])
+    try:
+        parts = np.load(path_npy, allow_pickle=False)              # a plain (non-object) array
+    except ValueError:
+        with open(path_npy, "rb") as fh:
+            major, _minor = np.lib.format.read_magic(fh)
+            (np.lib.format.read_array_header_1_0 if major == 1 else np.lib.format.read_array_header_2_0)(fh)
+            parts = _ArraysOnlyUnpickler(fh).load()
+    parts = [np.asarray(a) for a in parts]
+    if len(parts) != 3 or any(a.dtype.kind not in "iub" for a in parts):
+        raise ValueError(f"{path_npy}: expected three index arrays")
+    if all(a.dtype.kind == "b" for a in parts):
+        return np.ix_(*[a.reshape(-1) for a in parts])
+    return np.ix_(*[a.reshape(-1).astype(np.int64) for a in parts])
 
 
 def minibatch_graphs(samples):

@@ -61,9 +61,45 @@ def init_from_env(backend=None):
 
 def shard_indices(perm, step, per_rank, rank, world_size):
     """Indices of rank `rank` for global step `step`: the global batch is
-    perm[step*G:(step+1)*G] with G = per_rank*world_size, dealt round-robin (r::W)."""
+    perm[step*G:(step+1)*G] with G = per_rank*world_size, dealt round-robin (r::W).  The last
+    global batch of an epoch may be short; a rank whose share of it is empty gets []."""
     g = per_rank * world_size
     return list(perm[step * g:(step + 1) * g][rank::world_size])
+
+
+def broadcast_object(obj, src=0):
+    """`obj` of rank `src` on every rank (anything picklable: hyper-parameter tuples, seeds).
+    Identity when torch.distributed is not initialised."""
+    if world()[1] == 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def assert_same_layout(params, what="parameters"):
+    """Every rank must hold the same number of tensors with the same shapes before a collective
+    walks over them: a mismatch (e.g. ranks that drew different hyper-parameters) would otherwise
+    hang RCCL or silently train diverging replicas.  Raises RuntimeError on EVERY rank."""
+    rank, w = world()
+    if w == 1:
+        return
+    mine = [tuple(p.shape) for p in params]
+    everyone = [None] * w
+    dist.all_gather_object(everyone, mine)
+    bad = [r for r, shapes in enumerate(everyone) if shapes != everyone[0]]
+    if bad:
+        raise RuntimeError(f"{what} differ between ranks: rank 0 holds {len(everyone[0])} tensors, "
+                           f"ranks {bad} hold {[len(everyone[r]) for r in bad]} (or other shapes); "
+                           "build the model from ONE set of hyper-parameters (gts.dist.broadcast_object)")
+
+
+def broadcast_parameters(params, src=0):
+    """Identical replicas: rank `src`'s values win.  Checks the layouts first."""
+    params = list(params)
+    assert_same_layout(params)
+    for p in params:
+        dist.broadcast(p.data, src=src)
 
 
 class FlatGradSync:
@@ -109,6 +145,13 @@ class FlatGradSync:
             den = class_weights[labels].sum()
         num.backward()
         self._scalars = torch.stack([den.detach(), num.detach()])
+
+    def empty_step(self, device=None):
+        """This rank has no sample in the (short, last) global batch of the epoch: it contributes
+        zero gradients, numerator and denominator, and still takes part in the collective."""
+        for p in self.params:
+            p.grad = None
+        self._scalars = torch.zeros(2, dtype=torch.float32, device=device or self.params[0].device)
 
     def all_reduce_and_normalise(self):
         """One concatenation, one collective, one division; afterwards every rank holds the exact

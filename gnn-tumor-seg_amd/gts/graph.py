@@ -16,6 +16,8 @@ Layout (all int32, built once on the host, uploaded once per device):
 The max-pool argmax is stored as a slot (uint8 when max in-degree <= 254), which is why
 the backward needs t_slot; GAT's backward reads per-edge data through t_pos.
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -27,7 +29,7 @@ class _DeviceCSR:
     (a single host->device copy instead of eight) and handed out as views of it."""
 
     __slots__ = ("indptr", "indices", "t_indptr", "t_indices", "t_slot", "t_pos",
-                 "deg_clamped", "deg_plus1", "device", "packed")
+                 "deg_clamped", "deg_plus1", "device", "packed", "__weakref__")
     _INT_FIELDS = ("indptr", "indices", "t_indptr", "t_indices", "t_slot", "t_pos")
 
     def __init__(self, g, device):
@@ -73,7 +75,8 @@ class Graph:
         self._batch_num_nodes = list(batch_num_nodes) if batch_num_nodes is not None else [self.n]
         self.ndata = {}
         self.device = torch.device("cpu")
-        self._dev_cache = {}
+        self._dev_cache = {}              # device -> weakref(_DeviceCSR), shared by every view of this graph
+        self._dev = None                  # the strong reference lives on the device view that uses it
         if _prebuilt is not None:
             (self.indptr, self.indices, self.t_indptr, self.t_indices, self.t_slot,
              self.t_pos) = _prebuilt
@@ -148,26 +151,33 @@ class Graph:
                 torch.from_numpy(self.dst.astype(np.int64)).to(self.device))
 
     def to(self, device, **_kwargs):
-        """Return a view of this graph on `device`.  Host arrays are shared; the device copy
-        of the CSR is made once per (graph, device) and reused by later `.to` calls."""
+        """Return a view of this graph on `device`.  Host arrays are shared.  The device copy of the
+        CSR is uploaded on first use and shared by every live view on that device, but it is owned
+        by those views (the host graph only keeps a weak reference): a dataset that caches host
+        graphs does not pin ~3 MB of device memory per sample it has ever evaluated."""
         device = torch.device(device)
         if device.type == "cuda" and device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         out = Graph.__new__(Graph)
         out.__dict__.update(self.__dict__)
         out.device = device
+        out._dev = None
         out.ndata = {k: v.to(device) for k, v in self.ndata.items()}
         return out
 
     def dev(self):
-        """Device CSR for self.device (uploaded lazily, cached on the shared cache)."""
+        """Device CSR for self.device (uploaded lazily; kept alive by the views that use it)."""
         if self.device.type != "cuda":
             raise RuntimeError("Graph is on the CPU: call graph.to('cuda') first "
                                "(the gts operators have no CPU path)")
-        d = self._dev_cache.get(self.device)
-        if d is None:
-            d = _DeviceCSR(self, self.device)
-            self._dev_cache[self.device] = d
+        d = self._dev
+        if d is None or d.device != self.device:
+            ref = self._dev_cache.get(self.device)
+            d = ref() if ref is not None else None
+            if d is None:
+                d = _DeviceCSR(self, self.device)
+                self._dev_cache[self.device] = weakref.ref(d)
+            self._dev = d
         return d
 
     @property

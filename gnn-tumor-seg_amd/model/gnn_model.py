@@ -36,14 +36,21 @@ BATCH_SIZE = 6
 
 
 class _ShardedBatches:
-    """Epoch iterator for data-parallel runs: one shared shuffle, per-rank slices."""
+    """Epoch iterator for data-parallel runs: one shared shuffle, per-rank slices of every global
+    batch of `per_rank * world_size` samples.  Like the reference's `DataLoader(drop_last=False)`
+    (model/gnn_model.py:31) the trailing partial global batch IS trained on: it is dealt round-robin
+    too, and a rank whose share of it is empty yields None (it then contributes zero gradients and
+    zero loss weight to that step's all-reduce, so the weighted-CE normalisation stays exact)."""
 
     def __init__(self, dataset, per_rank, rank, world_size, seed=0):
         self.dataset, self.per_rank, self.rank, self.world = dataset, per_rank, rank, world_size
         self.seed, self.epoch = seed, 0
+        if len(dataset) == 0:
+            raise ValueError("the training dataset is empty: an epoch would have no step")
 
     def __len__(self):
-        return len(self.dataset) // (self.per_rank * self.world)
+        g = self.per_rank * self.world
+        return (len(self.dataset) + g - 1) // g
 
     def __iter__(self):
         gen = torch.Generator()
@@ -52,11 +59,18 @@ class _ShardedBatches:
         perm = torch.randperm(len(self.dataset), generator=gen).tolist()
         for step in range(len(self)):
             idx = gdist.shard_indices(perm, step, self.per_rank, self.rank, self.world)
-            yield minibatch_graphs([self.dataset[i] for i in idx])
+            yield minibatch_graphs([self.dataset[i] for i in idx]) if idx else None
 
 
 class GNN:
-    def __init__(self, model_type, hyperparameters, train_dataset, batch_size=BATCH_SIZE, prefetch=True):
+    """`batch_size` is the number of graphs ONE rank puts into a step (the reference's
+    BATCH_SIZE = 6, model/gnn_model.py:12).  Under torch.distributed with W ranks a step therefore
+    trains on a global batch of `batch_size * W` graphs (weak scaling, `global_batch_size`) with the
+    learning rate unchanged; pass `keep_global_batch=True` to split the reference's batch over the
+    ranks instead (per-rank batch ceil(batch_size / W), same optimisation problem as one GPU)."""
+
+    def __init__(self, model_type, hyperparameters, train_dataset, batch_size=BATCH_SIZE, prefetch=True,
+                 keep_global_batch=False):
         if not torch.cuda.is_available():
             raise RuntimeError("GNN needs an AMD GPU (MI355X): the HIP kernels have no CPU fallback")
         self.rank, self.world_size = gdist.world()
@@ -77,13 +91,17 @@ class GNN:
         # fused HIP pass (gts_weighted_ce_f32)
         self.loss_fcn = lambda logits, labels: gops.weighted_cross_entropy(logits, labels, class_weights)
         self.grad_sync = None
+        self.global_batch_size = batch_size
         if train_dataset is None:
             self.train_loader = None
         elif self.world_size > 1:
-            for p in self.net.parameters():  # identical replicas: rank 0's initialisation wins
-                torch.distributed.broadcast(p.data, src=0)
+            # identical replicas: rank 0's initialisation wins (after checking that every rank built
+            # the same architecture — ranks that drew different hyper-parameters must not reach RCCL)
+            gdist.broadcast_parameters(self.net.parameters(), src=0)
             self.grad_sync = gdist.FlatGradSync(self.net.parameters())
-            self.train_loader = _ShardedBatches(train_dataset, batch_size, self.rank, self.world_size)
+            per_rank = -(-batch_size // self.world_size) if keep_global_batch else batch_size
+            self.global_batch_size = per_rank * self.world_size
+            self.train_loader = _ShardedBatches(train_dataset, per_rank, self.rank, self.world_size)
         else:
             self.train_loader = DataLoader(train_dataset, batch_size=batch_size, shuffle=True,
                                            num_workers=0, collate_fn=minibatch_graphs)
@@ -99,6 +117,19 @@ class GNN:
             return loss.detach()
         self.grad_sync.zero_grad()
         self.grad_sync.weighted_ce_backward(logits, labels, self.class_weights)
+        loss = self.grad_sync.all_reduce_and_normalise()
+        if isinstance(self.optimizer, FlatAdamW):
+            self.optimizer.step(flat_grad=self.grad_sync.flat_gradients())
+        else:
+            self.optimizer.step()
+        return loss.clone()
+
+    def empty_step(self):
+        """Data-parallel step of a rank without samples (short last global batch): no forward, zero
+        contribution to the all-reduce, the same optimizer update as every other rank."""
+        if self.grad_sync is None:
+            raise RuntimeError("empty_step() only exists in data-parallel runs")
+        self.grad_sync.empty_step(self.device)
         loss = self.grad_sync.all_reduce_and_normalise()
         if isinstance(self.optimizer, FlatAdamW):
             self.optimizer.step(flat_grad=self.grad_sync.flat_gradients())
@@ -122,8 +153,8 @@ class GNN:
         stream while the main thread enqueues step i.  Same batches in the same order as iterating
         the loader directly (`prefetch=False`)."""
         if not self.prefetch:
-            for _ids, graph, feats, labels in self.train_loader:
-                yield self._to_device(graph, feats, labels)
+            for item in self.train_loader:
+                yield None if item is None else self._to_device(*item[1:])
             return
         import queue
         import threading
@@ -135,9 +166,13 @@ class GNN:
         def produce():
             try:
                 torch.cuda.set_device(device_index)
-                for _ids, graph, feats, labels in self.train_loader:
+                for item in self.train_loader:
                     if stop.is_set():
                         return
+                    if item is None:                       # no share of this (short) global batch
+                        slots.put((None, None))
+                        continue
+                    _ids, graph, feats, labels = item
                     with torch.cuda.stream(copy_stream):
                         batch = self._to_device(graph, feats, labels)
                         batch[0].dev()                     # CSR upload belongs to the copy as well
@@ -157,6 +192,9 @@ class GNN:
                     return
                 if isinstance(item, BaseException):
                     raise item
+                if item[0] is None:
+                    yield None
+                    continue
                 (graph, feats, labels), ready = item
                 main = torch.cuda.current_stream()
                 main.wait_event(ready)
@@ -176,7 +214,8 @@ class GNN:
         """One pass over the training loader; returns the mean of the per-step losses
         (reference :34-48).  Losses stay on the device until the epoch ends."""
         self.net.train()
-        step_losses = [self.train_step(graph, feats, labels) for graph, feats, labels in self._device_batches()]
+        step_losses = [self.empty_step() if batch is None else self.train_step(*batch)
+                       for batch in self._device_batches()]
         self.lr_decay.step()
         return np.mean(torch.stack(step_losses).cpu().double().numpy())
 

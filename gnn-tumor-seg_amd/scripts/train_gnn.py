@@ -89,7 +89,10 @@ def main(argv=None):
     dataset = ImageGraphDataset(os.path.expanduser(args.data_dir), args.data_prefix, read_image=False,
                                 read_graph=True, read_label=True)
     pick = generate_random_hyperparameters if args.random_hyperparams else populate_hardcoded_hyperparameters
-    hyperparams = pick(args.model_type)
+    # ONE draw for the whole job: the random search seeds itself from the wall clock of the calling
+    # process (utils/hyperparam_helpers.py), so ranks drawing on their own would build different
+    # networks.  Rank 0 draws, every rank receives its tuple.
+    hyperparams = gdist.broadcast_object(pick(args.model_type) if rank == 0 else None)
     progress_file_fd = f"{args.output_dir}{os.sep}{args.run_name}.txt"
     if rank == 0:
         create_run_progress_file(progress_file_fd, args.model_type, hyperparams)

@@ -1,5 +1,8 @@
 """ImageGraphDataset + collate on a synthetic on-disk dataset (host side, CPU)."""
+import os
+
 import numpy as np
+import pytest
 import torch
 
 from data_processing.data_loader import ImageGraphDataset, minibatch_graphs
@@ -51,3 +54,35 @@ def test_binary_graph_image_cache(tmp_path, monkeypatch):
         assert np.array_equal(getattr(a[1], name), getattr(b[1], name)), name
     assert np.array_equal(a[2], b[2]) and a[2].dtype == b[2].dtype and np.array_equal(a[3], b[3])
     assert torch.equal(a[1].ndata["norm"], b[1].ndata["norm"])
+
+
+def test_crop_files_load_without_the_general_pickle_loader(tmp_path):
+    """The reference writes `_crop.npy` as a pickled object array (scripts/preprocess_dataset.py:130).
+    It is read through an arrays-only unpickler; a plain `.npz` triple is preferred when present; a
+    file that smuggles any other global is refused."""
+    import pickle
+
+    from data_processing.data_loader import load_crop, save_crop
+
+    mask = np.zeros((30, 20, 10), dtype=bool)
+    mask[3:9, 4:15, 2:7] = True
+    crop = np.ix_(mask.any(axis=(1, 2)), mask.any(axis=(0, 2)), mask.any(axis=(0, 1)))
+    legacy = str(tmp_path / "a_crop.npy")
+    np.save(legacy, np.array(crop, dtype=object), allow_pickle=True)
+    got = load_crop(legacy)
+    assert len(got) == 3 and all(np.array_equal(a, b) for a, b in zip(got, crop))
+    assert np.zeros((30, 20, 10))[got].shape == (6, 11, 5)
+    save_crop(str(tmp_path / "b_crop.npz"), crop)
+    got = load_crop(str(tmp_path / "b_crop.npy"))                   # only the .npz exists
+    assert all(np.array_equal(a, b) for a, b in zip(got, crop))
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+
+    bad = str(tmp_path / "c_crop.npy")
+    with open(bad, "wb") as fh:
+        np.lib.format.write_array_header_1_0(fh, {"descr": "|O", "fortran_order": False, "shape": (3,)})
+        pickle.dump([Evil(), 1, 2], fh)
+    with pytest.raises(ValueError, match="refusing"):
+        load_crop(bad)

@@ -128,3 +128,93 @@ def test_shard_indices_partition():
         for step in range(64 // (per_rank * world)):
             got = sorted(i for r in range(world) for i in gdist.shard_indices(perm, step, per_rank, r, world))
             assert got == sorted(perm[step * per_rank * world:(step + 1) * per_rank * world])
+
+
+# ------------------------------------------------------------------ epoch plumbing of the DP run
+def _tgraph_of(g):
+    return torch_ref.TGraph(graph_ref.RefGraph(g.src, g.dst, g.n))
+
+
+def _epoch_worker(rank, world, port, n_samples, per_rank, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    gdist.init_from_env(backend="gloo")
+    from model.gnn_model import _ShardedBatches
+    from tests.dp_worker import MemDataset
+    from utils.hyperparam_helpers import generate_random_hyperparameters
+
+    # (1) ONE hyper-parameter draw for the job: rank 0's (the ranks would draw different ones)
+    own = generate_random_hyperparameters("GSpool", seed=10 + rank)
+    hp = gdist.broadcast_object(own if rank == 0 else None)
+    # (2) mismatched architectures are refused on every rank instead of reaching the collective
+    torch.manual_seed(rank)
+    odd = torch_ref.ref_init_graph_net("GSpool", HP(4, 4, [8] * (2 + rank), None, None))
+    try:
+        gdist.broadcast_parameters(odd.parameters())
+        refused = False
+    except RuntimeError as exc:
+        refused = "differ between ranks" in str(exc)
+    # (3) an epoch whose last global batch is short: every sample is trained on exactly once
+    net = torch_ref.ref_init_graph_net("GSpool", HP(20, 4, [16, 16], None, None))
+    gdist.broadcast_parameters(net.parameters())
+    sync = gdist.FlatGradSync(net.parameters())
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    loader = _ShardedBatches(MemDataset(n_samples, n=60), per_rank, rank, world)
+    seen, losses = [], []
+    for item in loader:
+        if item is None:
+            sync.empty_step()
+        else:
+            ids, g, feats, labels = item
+            seen += ids
+            sync.zero_grad()
+            sync.weighted_ce_backward(net(_tgraph_of(g), feats), labels, torch.tensor(W))
+        losses.append(float(sync.all_reduce_and_normalise()))
+        opt.step()
+    torch.save({"hp": tuple(map(str, hp)), "own": tuple(map(str, own)), "refused": refused, "seen": seen,
+                "losses": losses, "steps": len(loader), "params": [p.detach().clone() for p in net.parameters()]},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("n_samples,per_rank", [(5, 1), (7, 2), (1, 1)])
+def test_two_rank_epoch_keeps_the_partial_last_batch_and_one_hyperparameter_draw(tmp_path, n_samples, per_rank):
+    from model.gnn_model import _ShardedBatches
+    from tests.dp_worker import MemDataset
+    from utils.hyperparam_helpers import generate_random_hyperparameters
+
+    world = 2
+    mp.spawn(_epoch_worker, args=(world, _free_port(), n_samples, per_rank, str(tmp_path)), nprocs=world, join=True)
+    ranks = [torch.load(tmp_path / f"rank{r}.pt", weights_only=False) for r in range(world)]
+    want_hp = tuple(map(str, generate_random_hyperparameters("GSpool", seed=10)))
+    assert ranks[0]["hp"] == ranks[1]["hp"] == want_hp and ranks[1]["own"] != want_hp
+    assert ranks[0]["refused"] and ranks[1]["refused"]
+    g = per_rank * world
+    assert ranks[0]["steps"] == ranks[1]["steps"] == -(-n_samples // g)           # ceil: nothing dropped
+    assert sorted(ranks[0]["seen"] + ranks[1]["seen"]) == sorted(f"s{i}" for i in range(n_samples))
+    assert ranks[0]["losses"] == ranks[1]["losses"]
+    for a, b in zip(ranks[0]["params"], ranks[1]["params"]):
+        assert torch.equal(a, b)
+    # the same epoch in one process over the global batches (the reference's drop_last=False loader)
+    torch.manual_seed(0)                      # rank 0's initialisation (set by the worker's seed below)
+    data = MemDataset(n_samples, n=60)
+    single = _ShardedBatches(data, g, 0, 1)
+    torch.manual_seed(0)
+    torch_ref.ref_init_graph_net("GSpool", HP(4, 4, [8] * 2, None, None))     # rank 0 built `odd` first
+    net = torch_ref.ref_init_graph_net("GSpool", HP(20, 4, [16, 16], None, None))
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    losses = []
+    for ids, graph, feats, labels in single:
+        opt.zero_grad()
+        loss = F.cross_entropy(net(_tgraph_of(graph), feats), labels, weight=torch.tensor(W))
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert np.allclose(losses, ranks[0]["losses"], rtol=1e-5, atol=1e-7)
+    for p, q in zip(net.parameters(), ranks[0]["params"]):
+        assert torch.allclose(p.detach(), q, rtol=1e-4, atol=1e-6)
+    with pytest.raises(ValueError):
+        _ShardedBatches(MemDataset(0), 1, 0, 2)

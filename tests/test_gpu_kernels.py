@@ -325,3 +325,19 @@ def test_weighted_cross_entropy_matches_torch(n, c, weighted):
     a = ops.weighted_cross_entropy(x.to(DEV), y.to(DEV), None if w is None else w.to(DEV))
     b = ops.weighted_cross_entropy(x.to(DEV), y.to(DEV), None if w is None else w.to(DEV))
     assert torch.equal(a, b)                      # deterministic reduction
+
+
+def test_device_csr_is_owned_by_the_device_views_not_by_the_cached_host_graph():
+    """A dataset caches host graphs; their device CSRs must go away with the last device view."""
+    import gc
+    import weakref
+
+    host = gts.Graph(*random_coo(200, 900, seed=5), 200)
+    view = host.to(DEV)
+    csr = view.dev()
+    assert host.to(DEV).dev() is csr and view.dev() is csr      # one upload, shared while in use
+    alive = weakref.ref(csr)
+    del view, csr
+    gc.collect()
+    assert alive() is None and host.device.type == "cpu"
+    assert host.to(DEV).dev().indptr.numel() == 201             # and it is rebuilt on demand
