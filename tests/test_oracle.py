@@ -126,3 +126,105 @@ def test_lin_before_mp_branch_is_algebraically_the_same():
     x = torch.randn(10, 8, dtype=torch.float64)
     after = layer.fc_self(x) + layer.fc_neigh(torch_ref.spmm_mean(g, x)) + layer.bias
     assert torch.allclose(layer(g, x), after, atol=1e-12)
+
+
+# ------------------------------------------------------------------ independent dense formulation
+# Guard against restatement slips in oracle/torch_ref.py (it does NOT lift "parity unpinned": DGL is
+# still absent): every layer is recomputed in fp64 from a dense adjacency matrix — A[v, u] = number
+# of edges u -> v, `A @ x`, a masked softmax over a dense [N, N, H] score tensor — which shares no
+# code with the CSR / slot-order formulation of the oracle.
+def _dense_case(seed, ties=False):
+    n = 30
+    src, dst = random_coo(n, 90, seed=seed)
+    dst[dst == 7] = 8                                   # node 7: zero in-degree
+    src, dst = np.concatenate([src, [3, 11, 11]]), np.concatenate([dst, [3, 11, 12]])   # self-loops (+1 edge)
+    ref = graph_ref.RefGraph(src, dst, n)
+    a = torch.zeros(n, n, dtype=torch.float64)
+    a.index_put_((torch.from_numpy(dst), torch.from_numpy(src)), torch.ones(len(src), dtype=torch.float64),
+                 accumulate=True)
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randint(-2, 3, (n, 6), generator=gen).double() if ties else torch.randn(n, 6, generator=gen).double()
+    return torch_ref.TGraph(ref), a, x
+
+
+def _dense_sage(layer, a, h):
+    deg = a.sum(1, keepdim=True)
+    lin_first = layer._in > layer._out
+    if layer._aggre_type == "pool":
+        p = torch.relu(h @ layer.fc_pool.weight.t() + layer.fc_pool.bias)
+        masked = torch.where(a[:, :, None] > 0, p[None, :, :], torch.full((), -float("inf"), dtype=h.dtype))
+        m = masked.amax(dim=1)
+        m = torch.where(torch.isinf(m), torch.zeros_like(m), m)          # no in-edge -> 0
+        return h @ layer.fc_self.weight.t() + m @ layer.fc_neigh.weight.t() + layer.bias
+    s = h @ layer.fc_neigh.weight.t() if lin_first else h
+    if layer._aggre_type == "mean":
+        neigh = (a @ s) / deg.clamp(min=1)
+    else:
+        neigh = (a @ s + s) / (deg + 1)
+    if not lin_first:
+        neigh = neigh @ layer.fc_neigh.weight.t()
+    return (neigh if layer._aggre_type == "gcn" else h @ layer.fc_self.weight.t() + neigh) + layer.bias
+
+
+@pytest.mark.parametrize("aggr", ["pool", "mean", "gcn"])
+@pytest.mark.parametrize("fout", [4, 9])                # 6 -> 4 takes the lin_before_mp branch
+def test_sage_layers_equal_a_dense_adjacency_formulation(aggr, fout):
+    for ties in (False, True):
+        g, a, x = _dense_case(seed=fout, ties=ties)
+        torch.manual_seed(fout)
+        layer = torch_ref.RefSAGEConv(6, fout, aggr).double()
+        with torch.no_grad():
+            layer.bias.normal_()
+        xr = x.clone().requires_grad_(True)
+        out = layer(g, xr)
+        xd = x.clone().requires_grad_(True)
+        want = _dense_sage(layer, a, xd)
+        assert torch.allclose(out, want, rtol=1e-12, atol=1e-12)
+        # node 7 has no in-edge: the neighbour term is 0 (pool / mean) or the node itself (gcn)
+        lone = x[7] @ (layer.fc_neigh if aggr == "gcn" else layer.fc_self).weight.t() + layer.bias
+        assert torch.allclose(out[7].detach(), lone.detach(), rtol=1e-12, atol=1e-12)
+        if ties and aggr == "pool":
+            continue      # torch.amax splits a tie's gradient evenly; the first-maximum rule has its own tests
+        gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).double()
+        grads = torch.autograd.grad(out, [xr, *layer.parameters()], gout)
+        wants = torch.autograd.grad(want, [xd, *layer.parameters()], gout)
+        for got, exp in zip(grads, wants):
+            assert torch.allclose(got, exp, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("heads,dim,residual,fin", [(3, 5, False, 6), (2, 3, True, 6), (1, 4, True, 4)])
+def test_gat_layer_equals_a_dense_masked_softmax_formulation(heads, dim, residual, fin):
+    n = 30
+    src, dst = random_coo(n, 80, seed=heads, min_in_degree=1)
+    src, dst = np.concatenate([src, [5, 5]]), np.concatenate([dst, [5, 6]])     # a self-loop
+    g = torch_ref.TGraph(graph_ref.RefGraph(src, dst, n))
+    a = torch.zeros(n, n, dtype=torch.float64)
+    a.index_put_((torch.from_numpy(dst), torch.from_numpy(src)), torch.ones(len(src), dtype=torch.float64),
+                 accumulate=True)
+    torch.manual_seed(dim)
+    layer = torch_ref.RefGATConv(fin, dim, heads, residual=residual, activation=torch.nn.functional.elu).double()
+    with torch.no_grad():
+        layer.bias.normal_()
+    x = torch.randn(n, fin, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    out = layer(g, xr)
+
+    xd = x.clone().requires_grad_(True)
+    ft = (xd @ layer.fc.weight.t()).view(n, heads, dim)
+    el = (ft * layer.attn_l).sum(-1)
+    er = (ft * layer.attn_r).sum(-1)
+    score = torch.nn.functional.leaky_relu(el[None, :, :] + er[:, None, :], 0.2)          # [v, u, h]
+    score = torch.where(a[:, :, None] > 0, score, torch.full((), -float("inf"), dtype=torch.float64))
+    w = a[:, :, None] * torch.exp(score - score.amax(dim=1, keepdim=True).detach())       # multiplicity counts
+    w = w / w.sum(dim=1, keepdim=True)
+    want = torch.einsum("vuh,uhd->vhd", w, ft)
+    if residual:
+        res = xd if fin == heads * dim else xd @ layer.res_fc.weight.t()
+        want = want + res.view(n, heads, dim)
+    want = torch.nn.functional.elu(want + layer.bias.view(1, heads, dim))
+    assert torch.allclose(out, want, rtol=1e-12, atol=1e-12)
+    gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(2)).double()
+    grads = torch.autograd.grad(out, [xr, *layer.parameters()], gout)
+    wants = torch.autograd.grad(want, [xd, *layer.parameters()], gout)
+    for got, exp in zip(grads, wants):
+        assert torch.allclose(got, exp, rtol=1e-9, atol=1e-12)
