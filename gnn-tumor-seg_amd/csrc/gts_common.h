@@ -52,6 +52,17 @@ struct Vec<1> {
   __device__ __forceinline__ static Vec load_nt(const float* p) { return Vec{{__builtin_nontemporal_load(p)}}; }
 };
 
+// Entry `index` of an array member of the kernel's (single, by-value) argument struct, read
+// straight from the kernarg segment with a scalar load.  Indexing the by-value copy with a
+// runtime value would make the compiler move the whole struct to scratch memory.
+template <typename T>
+__device__ __forceinline__ T kernarg_entry(size_t member_offset, int index) {
+  typedef const __attribute__((address_space(4))) char* KernargBytes;
+  typedef const __attribute__((address_space(4))) T* KernargT;
+  KernargBytes base = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr();
+  return *(KernargT)(base + member_offset + sizeof(T) * index);
+}
+
 inline int launch_status() {
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? GTS_OK : static_cast<int>(e);

@@ -60,17 +60,6 @@ struct GemmArgs {
 #endif
 };
 
-// Entry `index` of an array member of the kernel's (single, by-value) argument struct, read
-// straight from the kernarg segment with a scalar load.  Indexing the by-value copy with a
-// runtime value would make the compiler move the whole struct to scratch memory.
-template <typename T>
-__device__ __forceinline__ T kernarg_entry(size_t member_offset, int index) {
-  typedef const __attribute__((address_space(4))) char* KernargBytes;
-  typedef const __attribute__((address_space(4))) T* KernargT;
-  KernargBytes base = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr();
-  return *(KernargT)(base + member_offset + sizeof(T) * index);
-}
-
 template <int ROWS, bool KC, int THREADS>
 struct OperandTile {
   static constexpr int kFloats = KC ? ROWS * kKcLd : kBK * ROWS;
@@ -688,6 +677,28 @@ extern "C" int32_t gts_linear_bwd_input_f32(const float* g0, const float* w0, co
   p.mask = relu_mask;
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
   return launch_plain<true, false>(p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t gts_linear_bwd_input_t_f32(const float* g0, const float* w0t, const float* g1,
+                                              const float* w1t, const float* relu_mask, float* gin,
+                                              int64_t m, int64_t k, int64_t n0, int64_t n1,
+                                              void* stream) {
+  using namespace gts;
+  if (!g0 || !w0t || !gin || ((g1 == nullptr) != (w1t == nullptr))) return GTS_ERR_NULL;
+  if (m < 0 || k <= 0 || n0 <= 0 || n1 < 0 || m >= (1LL << 31) || k >= (1 << 20) ||
+      n0 >= (1 << 20) || n1 >= (1 << 20) || !aligned4(k) || !aligned4(n0) || !aligned4(n1) ||
+      (g1 && n1 == 0))
+    return GTS_ERR_SHAPE;
+  if (m == 0) return GTS_OK;
+  GemmArgs p{};
+  // C[m, k] = sum_n g[m, n] * Wt[k, n]: the forward form (both operands reduction-contiguous)
+  p.a[0] = g0, p.b[0] = w0t, p.lda[0] = p.ldb[0] = static_cast<int>(n0), p.kseg[0] = static_cast<int>(n0);
+  p.a[1] = g1 ? g1 : g0, p.b[1] = w1t ? w1t : w0t;
+  p.lda[1] = p.ldb[1] = static_cast<int>(n1), p.kseg[1] = g1 ? static_cast<int>(n1) : 0;
+  p.ra = static_cast<int>(m), p.rb = static_cast<int>(k), p.c = gin, p.ldc = static_cast<int>(k);
+  p.mask = relu_mask;
+  p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
+  return launch_plain<true, true>(p, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t gts_linear_bwd_weight_workspace(int64_t m, int64_t n, int64_t k,

@@ -122,6 +122,48 @@ def linear_bwd_input(g0, w0, g1=None, w1=None, relu_mask=None):
     return gin if kp == k else gin[:, :k].contiguous()
 
 
+def transpose_batch(mats):
+    """[w [R,C], ...] (one shape) -> [w^T [C,R], ...] as views of ONE new buffer, one launch per 32."""
+    import ctypes
+
+    if not mats:
+        return []
+    rows, cols = mats[0].shape
+    mats = [m.contiguous() for m in mats]
+    dev = _chk(*mats)
+    for m in mats:
+        _same(tuple(m.shape), (rows, cols), "matrices of one transpose batch")
+    out = torch.empty((len(mats), cols, rows), dtype=torch.float32, device=dev)
+    arr = ctypes.c_void_p * len(mats)
+    check(_lib.load().gts_transpose_batch_f32(arr(*[ptr(m) for m in mats]), arr(*[ptr(out[q]) for q in range(len(mats))]),
+                                              len(mats), rows, cols, current_stream()), "gts_transpose_batch_f32")
+    return list(out.unbind(0))
+
+
+def linear_bwd_input_t(g0, w0t, g1=None, w1t=None, relu_mask=None):
+    """linear_bwd_input from TRANSPOSED weights (w0t [K,N0] = w0.t(), from transpose_batch): the
+    GEMM then runs in the forward kernel's form.  Same values, bit for bit.  All widths % 4 == 0."""
+    _same(_mat(g0, "g0").shape[1], _mat(w0t, "w0t").shape[1], "inner dims of g0 @ w0t^T")
+    if (g1 is None) != (w1t is None):
+        raise _lib.GtsError("g1 and w1t go together")
+    if g1 is not None:
+        _same(_mat(g1, "g1").shape[1], _mat(w1t, "w1t").shape[1], "inner dims of g1 @ w1t^T")
+        _same(g1.shape[0], g0.shape[0], "rows of g0 / g1")
+        _same(w1t.shape[0], w0t.shape[0], "rows of w0t / w1t")
+    m, k = g0.shape[0], w0t.shape[0]
+    if relu_mask is not None:
+        _same(tuple(relu_mask.shape), (m, k), "relu_mask vs result")
+    n0, n1 = g0.shape[1], g1.shape[1] if g1 is not None else 0
+    if k % 4 or n0 % 4 or n1 % 4:
+        raise _lib.GtsError("linear_bwd_input_t needs widths that are multiples of 4 (use linear_bwd_input)")
+    dev = _chk(g0, w0t, g1, w1t, relu_mask)
+    gin = torch.empty((m, k), dtype=torch.float32, device=dev)
+    _timed("igrad", 2.0 * m * k * (n0 + n1), lambda: check(
+        _lib.load().gts_linear_bwd_input_t_f32(ptr(g0), ptr(w0t), ptr(g1), ptr(w1t), ptr(relu_mask), ptr(gin),
+                                               m, k, n0, n1, current_stream()), "gts_linear_bwd_input_t_f32"))
+    return gin
+
+
 MAX_WGRAD_PROBLEMS = 32   # kMaxProblems of csrc/gts_gemm.hip
 
 

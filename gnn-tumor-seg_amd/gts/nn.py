@@ -60,6 +60,8 @@ class _SagePoolLayer(torch.autograd.Function):
 # CUs from the input-gradient chain it was meant to fill in behind (757 graphs/s with it, 777-789
 # without, profiles/r01_tune_gemm.log).
 OVERLAP_WEIGHT_GRADS = os.environ.get("GTS_OVERLAP_WGRAD", "0") != "0"
+# GTS_TRANSPOSED_IGRAD=0 keeps the strided-weight input-gradient kernel in the fused stack (A/B runs).
+TRANSPOSED_IGRAD = os.environ.get("GTS_TRANSPOSED_IGRAD", "1") != "0"
 _side_streams = {}
 
 
@@ -131,6 +133,25 @@ class _SagePoolStack(torch.autograd.Function):
         keep_alive = []
         deferred = {}                    # (N, K) -> [(g [M,N], a [M,K], want_bias, grads slot, bias slot)]
 
+        # Input gradients run in the forward GEMM's form on transposed weights (one batched
+        # transpose per weight shape and backward pass; wide outputs only — the 4-wide first /
+        # last layers keep the strided-operand kernel).
+        turned = {}
+        if TRANSPOSED_IGRAD:
+            by_shape = {}
+            for w in (params[5 * i + j] for i in range(n) for j in (0, 2, 3)):
+                if w.shape[1] >= 128 and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0:
+                    by_shape.setdefault(tuple(w.shape), []).append(w)
+            for ws in by_shape.values():
+                for w, wt in zip(ws, dense.transpose_batch(ws)):
+                    turned[id(w)] = wt
+
+        def igrad(g0, w0, g1=None, w1=None, relu_mask=None):
+            if id(w0) in turned and (w1 is None or id(w1) in turned) and g0.is_contiguous():
+                return dense.linear_bwd_input_t(g0, turned[id(w0)], g1, turned[id(w1)] if w1 is not None else None,
+                                                relu_mask=relu_mask)
+            return dense.linear_bwd_input(g0, w0, g1, w1, relu_mask=relu_mask)
+
         def defer(grad_out, act, slot, bias_slot):
             key = (grad_out.shape[1], act.shape[1])
             deferred.setdefault(key, []).append((grad_out, act, bias_slot is not None, slot, bias_slot))
@@ -138,7 +159,7 @@ class _SagePoolStack(torch.autograd.Function):
         for i in reversed(range(n)):
             h, m, arg = acts[3 * i:3 * i + 3]
             w_pool, _b_pool, w_self, w_neigh, _bias = params[5 * i:5 * i + 5]
-            gm = dense.linear_bwd_input(g, w_neigh)
+            gm = igrad(g, w_neigh)
             gp = ops.spmm_max_bwd(ctx.g, gm, arg)       # ReLU'(p) is already in the winner record
             if side is None:
                 defer(gp, h, 5 * i, 5 * i + 1)          # fc_pool.weight, fc_pool.bias
@@ -153,9 +174,9 @@ class _SagePoolStack(torch.autograd.Function):
                 keep_alive.append((g, gp))              # still being read by the side stream
                 grads[5 * i:5 * i + 5] = [g_wp, g_bp, g_ws, g_wn, g_bias]
             if i > 0:      # h is layer i-1's ReLU output: its backward is the mask h > 0
-                g = dense.linear_bwd_input(g, w_self, gp, w_pool, relu_mask=h)
+                g = igrad(g, w_self, gp, w_pool, relu_mask=h)
             elif ctx.needs_input_grad[1]:
-                gx = dense.linear_bwd_input(g, w_self, gp, w_pool)
+                gx = igrad(g, w_self, gp, w_pool)
         for problems in deferred.values():
             results = dense.linear_bwd_weight_multi([(go, act, want) for go, act, want, _, _ in problems])
             for (gw, gb), (_, _, _, slot, bias_slot) in zip(results, problems):

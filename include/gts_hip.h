@@ -211,6 +211,17 @@ int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const float* a1, co
 int32_t gts_linear_bwd_input_f32(const float* g0, const float* w0, const float* g1, const float* w1,
                                  const float* relu_mask, float* gin, int64_t m, int64_t k,
                                  int64_t n0, int64_t n1, void* stream);
+/* the same input gradient from TRANSPOSED weights (w0t [K,N0], w1t [K,N1], e.g. made once per
+ * backward pass by gts_transpose_batch_f32): both GEMM operands are then reduction-contiguous, the
+ * forward kernel's form — bitwise the same sums in the same order as gts_linear_bwd_input_f32. */
+int32_t gts_linear_bwd_input_t_f32(const float* g0, const float* w0t, const float* g1, const float* w1t,
+                                   const float* relu_mask, float* gin, int64_t m, int64_t k,
+                                   int64_t n0, int64_t n1, void* stream);
+/* dst[q][c, r] = src[q][r, c] for n_mats matrices of one shape [rows, cols] in one launch per 32
+ * (src, dst: HOST arrays of device pointers).  Serves the transposed-weight form above: the
+ * weights of a layer stack (torch Linear layout [out, in]) are turned once per backward pass. */
+int32_t gts_transpose_batch_f32(const float* const* src, float* const* dst, int32_t n_mats,
+                                int64_t rows, int64_t cols, void* stream);
 /* weight gradients of n_problems (1..32) same-shape problems in ONE launch (the three weight
  * gradients of a SAGE layer, or those of a whole stack of equal layers):  gw[q][n, k] = sum_m g[q][m,n] a[q][m,k];
  * gb[q][n] = sum_m g[q][m,n] where gb && gb[q].  g, a, gw, gb are HOST arrays of device pointers.

@@ -152,3 +152,35 @@ def test_unaligned_width_is_padded_on_the_host():
     gx = dense.linear_bwd_input(_rand(50, 7, seed=3).to(DEV), w.to(DEV))
     assert gx.shape == (50, 5)
     assert torch.allclose(gx.cpu(), _rand(50, 7, seed=3) @ w, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,cols,count", [(256, 256, 19), (4, 256, 2), (37, 50, 35), (1, 1, 1)])
+def test_transpose_batch(rows, cols, count):
+    mats = [_rand(rows, cols, seed=q).to(DEV) for q in range(count)]
+    outs = dense.transpose_batch(mats)
+    assert len(outs) == count
+    for m, t in zip(mats, outs):
+        assert t.shape == (cols, rows) and t.is_contiguous() and torch.equal(t, m.t())
+
+
+@pytest.mark.parametrize("m,k,n0,n1,mask", [(60000, 256, 256, 256, True), (60000, 256, 256, 0, False),
+                                            (49999, 132, 260, 64, True), (300, 256, 4, 256, False),
+                                            (120000, 256, 256, 256, True)])
+def test_input_gradient_from_transposed_weights_is_bitwise_the_strided_form(m, k, n0, n1, mask):
+    """gts_linear_bwd_input_t_f32 (forward-form kernel on W^T) against gts_linear_bwd_input_f32 and fp64."""
+    g0, w0 = _rand(m, n0, seed=1).to(DEV), _rand(n0, k, seed=2).to(DEV)
+    g1, w1 = (_rand(m, n1, seed=3).to(DEV), _rand(n1, k, seed=4).to(DEV)) if n1 else (None, None)
+    rm = _rand(m, k, seed=5).to(DEV) if mask else None
+    want = dense.linear_bwd_input(g0, w0, g1, w1, relu_mask=rm)
+    w0t = dense.transpose_batch([w0])[0]
+    w1t = dense.transpose_batch([w1])[0] if n1 else None
+    got = dense.linear_bwd_input_t(g0, w0t, g1, w1t, relu_mask=rm)
+    assert torch.equal(got, want)
+    ref = g0.cpu().double() @ w0.cpu().double()
+    bound = g0.cpu().double().abs() @ w0.cpu().double().abs()
+    if n1:
+        ref += g1.cpu().double() @ w1.cpu().double()
+        bound += g1.cpu().double().abs() @ w1.cpu().double().abs()
+    if mask:
+        ref = ref * (rm.cpu() > 0)
+    _check(got, ref, bound)
