@@ -55,9 +55,13 @@ struct GemmArgs {
   int tiles_n;          // output tiles along rb per problem
   int n_splits;
   int tiles_per_split;  // reduction tiles handled by one blockIdx.z
-#ifdef GTS_GEMM_STAMPS
-  unsigned long long* stamps;  // diagnostic build only: 4 x s_memrealtime per workgroup
-#endif
+};
+
+// Phase probe of the kernel (start / operands staged / main loop done / tile stored).  The
+// library only ever instantiates NoProbe, which compiles to nothing; tools/diag/gemm_probe.hip
+// includes this file and instantiates the same kernels with a probe that records timestamps.
+struct NoProbe {
+  __device__ __forceinline__ static void mark(int /*phase*/) {}
 };
 
 template <int ROWS, bool KC, int THREADS>
@@ -207,7 +211,7 @@ constexpr int min_waves_per_simd(int wm, int wn, int tm, int tn) {
 //   t&1, tile t+1 (already in registers) is written to the other image and tile t+2 is requested
 //   from memory, so a workgroup that is alone on its CU (256 x 256 tiles, 16 waves: one round
 //   over the 60 000-row matrices) keeps its matrix cores fed without a partner.
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, bool DB = false>
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, bool DB = false, class Probe = NoProbe>
 __global__ __launch_bounds__(64 * WM * WN, DB ? WM * WN / 4 : min_waves_per_simd(WM, WN, BM / WM / 32, BN / WN / 32))
 void gemm_kernel(const GemmArgs p) {
   constexpr int THREADS = 64 * WM * WN;
@@ -285,10 +289,7 @@ void gemm_kernel(const GemmArgs p) {
     }
   };
 
-#ifdef GTS_GEMM_STAMPS
-  const size_t stamp_at = 4 * (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x);
-  if (threadIdx.x == 0 && p.stamps) p.stamps[stamp_at] = __builtin_amdgcn_s_memrealtime();
-#endif
+  Probe::mark(0);
   auto stash = [&](int image) {
     TA::store(ra, lds + image * kImage);
     TB::store(rb, lds + image * kImage + TA::kFloats);
@@ -303,9 +304,7 @@ void gemm_kernel(const GemmArgs p) {
     }
     __syncthreads();
   }
-#ifdef GTS_GEMM_STAMPS
-  if (threadIdx.x == 0 && p.stamps) p.stamps[stamp_at + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
+  Probe::mark(1);
   if constexpr (DB) {
     for (int t = t_beg; t < t_end; ++t) {
       const int cur = (t - t_beg) & 1;
@@ -335,15 +334,10 @@ void gemm_kernel(const GemmArgs p) {
     }
   }
 
-#ifdef GTS_GEMM_STAMPS
-  if (threadIdx.x == 0 && p.stamps) p.stamps[stamp_at + 2] = __builtin_amdgcn_s_memrealtime();
-#endif
+  Probe::mark(2);
   const size_t slab = p.n_problems ? static_cast<size_t>(problem) * p.n_splits + blockIdx.z : 0;
   write_tile<BM, BN, WM, WN>(p, lds, p.c + slab * p.ra * p.ldc, acc, m0, n0);
-#ifdef GTS_GEMM_STAMPS
-  __syncthreads();
-  if (threadIdx.x == 0 && p.stamps) p.stamps[stamp_at + 3] = __builtin_amdgcn_s_memrealtime();
-#endif
+  Probe::mark(3);
   if (want_colsum) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -352,6 +346,202 @@ void gemm_kernel(const GemmArgs p) {
       if ((lane >> 5) == 0 && row < p.ra) p.colsum[slab * p.ra + row] = total;
     }
   }
+}
+
+// ---- 240-row panels on v_mfma_f32_16x16x4_f32 -------------------------------------------------
+// The layer GEMMs of the path have 60 000 (or 120 000) rows and 256 columns: with 256-row tiles
+// that is 235 workgroups for 256 CUs — 21 CUs idle and every busy CU carrying 256 rows where
+// 234.4 would do.  Row panels of 240 = 15 x 16 rows make it 250 workgroups of 240 rows (60 000 =
+// 250 x 240 exactly): -6 % rows per CU.  240 is not a multiple of 32, so this kernel is built
+// on the 16x16x4 MFMA (same flops per cycle as 32x32x2, exact fp32): 12 waves (3 x 4), one
+// wave = 80 x 64 outputs = 5 x 4 tiles, 3 waves per SIMD, 5 x 4 x 4 = 80 accumulator registers.
+// Forward form only (both operands reduction-contiguous; input gradients reach it through
+// transposed weights), two LDS images per operand and one barrier per reduction tile like the
+// double-buffered 256 x 256 tile.  Reduction index consumed by MFMA step (g, j) on lane
+// quarter q: 16 g + 4 q + j for both operands (one ds_read_b128 per operand tile and 4 MFMAs).
+typedef float v4acc __attribute__((ext_vector_type(4)));
+
+constexpr int kR240 = 240, kC240 = 256, kWm240 = 3, kWn240 = 4, kThreads240 = 64 * kWm240 * kWn240;
+constexpr int kTm240 = kR240 / kWm240 / 16, kTn240 = kC240 / kWn240 / 16;   // 5 x 4 tiles per wave
+constexpr int kStage240 = 16 * (kC240 / kWn240 + 4);                       // per-wave epilogue patch [16][68]
+
+template <class Probe = NoProbe>
+__global__ __launch_bounds__(kThreads240, kWm240 * kWn240 / 4) void gemm_rows240_kernel(const GemmArgs p) {
+  constexpr int kAFloats = kR240 * kKcLd, kBFloats = kC240 * kKcLd, kImage = kAFloats + kBFloats;
+  constexpr int kAVec = (kR240 + 95) / 96, kBVec = (kC240 + 95) / 96;       // 3 + 3 float4 per thread and tile
+  static_assert(kThreads240 == 8 * 96, "the loader assumes 96 rows of 8 float4 per pass");
+  static_assert(2 * kImage >= kWm240 * kWn240 * kStage240, "epilogue patches reuse the operand area");
+  __shared__ float lds[2 * kImage];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / kWn240, wn = wave % kWn240;
+  const int i16 = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.x * kR240, n0 = blockIdx.y * kC240;
+  const int row_end = min(p.ra, m0 + kR240);       // rows past the panel belong to the next workgroup
+  const int nt0 = (p.kseg[0] + kBK - 1) / kBK, nt1 = (p.kseg[1] + kBK - 1) / kBK;
+  const int n_tiles = nt0 + nt1;
+
+  v4acc acc[kTm240][kTn240];
+#pragma unroll
+  for (int tm = 0; tm < kTm240; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < kTn240; ++tn) acc[tm][tn] = v4acc{0.f, 0.f, 0.f, 0.f};
+
+  // Operand staging.  768 threads, 8 float4 per 32-wide row: thread t owns (row t >> 3, columns
+  // 4 (t & 7) ..) of three row groups 96 rows apart, so one lane offset serves every slot and the
+  // slot / panel / reduction-tile part of the address is wave-uniform.
+  const int r0 = threadIdx.x >> 3, kk = (threadIdx.x & 7) * 4;
+  bool a_ok[kAVec], b_ok[kBVec];
+#pragma unroll
+  for (int s = 0; s < kAVec; ++s) a_ok[s] = r0 + 96 * s < kR240 && m0 + r0 + 96 * s < row_end;
+#pragma unroll
+  for (int s = 0; s < kBVec; ++s) b_ok[s] = r0 + 96 * s < kC240 && n0 + r0 + 96 * s < p.rb;
+  v4f ra[kAVec], rb[kBVec];
+  auto fetch = [&](int t) {
+    const bool second = t >= nt0;
+    const int lda = second ? p.lda[1] : p.lda[0], ldb = second ? p.ldb[1] : p.ldb[0];
+    const int k0 = (second ? t - nt0 : t) * kBK, n_k = second ? p.kseg[1] : p.kseg[0];
+    const float* a = (second ? p.a[1] : p.a[0]) + static_cast<size_t>(m0) * lda + k0;   // uniform
+    const float* b = (second ? p.b[1] : p.b[0]) + static_cast<size_t>(n0) * ldb + k0;
+    const unsigned off_a = static_cast<unsigned>(r0) * lda + kk, off_b = static_cast<unsigned>(r0) * ldb + kk;
+    const bool k_ok = k0 + kk < n_k;
+#pragma unroll
+    for (int s = 0; s < kAVec; ++s)
+      ra[s] = (a_ok[s] && k_ok) ? *reinterpret_cast<const v4f*>(a + static_cast<size_t>(96 * s) * lda + off_a)
+                                : v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < kBVec; ++s)
+      rb[s] = (b_ok[s] && k_ok) ? *reinterpret_cast<const v4f*>(b + static_cast<size_t>(96 * s) * ldb + off_b)
+                                : v4f{0.f, 0.f, 0.f, 0.f};
+  };
+  const int lds_slot = r0 * kKcLd + kk;
+  auto stash = [&](int image) {
+    float* la = lds + image * kImage + lds_slot;
+    float* lb = la + kAFloats;
+#pragma unroll
+    for (int s = 0; s < kAVec; ++s)
+      if (r0 + 96 * s < kR240) *reinterpret_cast<v4f*>(la + 96 * s * kKcLd) = ra[s];
+#pragma unroll
+    for (int s = 0; s < kBVec; ++s)
+      if (r0 + 96 * s < kC240) *reinterpret_cast<v4f*>(lb + 96 * s * kKcLd) = rb[s];
+  };
+  // Per 16-deep reduction group: the wave's five A fragments stay in registers while the four B
+  // fragments pass through one at a time (the next one is requested before the current one's 20
+  // MFMAs are issued).  Consecutive MFMAs write different accumulators.
+  auto compute = [&](int image) {
+    const float* la = lds + image * kImage + (wm * (kR240 / kWm240) + i16) * kKcLd + 4 * q;
+    const float* lb = lds + image * kImage + kAFloats + (wn * (kC240 / kWn240) + i16) * kKcLd + 4 * q;
+#pragma unroll
+    for (int g = 0; g < kBK / 16; ++g) {
+      v4f af[kTm240];
+#pragma unroll
+      for (int tm = 0; tm < kTm240; ++tm) af[tm] = *reinterpret_cast<const v4f*>(la + tm * 16 * kKcLd + g * 16);
+      v4f bf = *reinterpret_cast<const v4f*>(lb + g * 16);
+#pragma unroll
+      for (int tn = 0; tn < kTn240; ++tn) {
+        v4f next = bf;
+        if (tn + 1 < kTn240) next = *reinterpret_cast<const v4f*>(lb + (tn + 1) * 16 * kKcLd + g * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int tm = 0; tm < kTm240; ++tm)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tm][j], bf[j], acc[tm][tn], 0, 0, 0);
+        bf = next;
+      }
+    }
+  };
+
+  Probe::mark(0);
+  if (n_tiles > 0) {
+    fetch(0);
+    stash(0);
+    if (n_tiles > 1) fetch(1);
+    __syncthreads();
+  }
+  Probe::mark(1);
+  for (int t = 0; t < n_tiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < n_tiles) stash(cur ^ 1);   // tile t+1: requested one iteration ago
+    if (t + 2 < n_tiles) fetch(t + 2);     // lands under the MFMAs below
+    compute(cur);
+    __syncthreads();                       // image cur^1 complete; everyone is done reading image cur
+  }
+  Probe::mark(2);
+
+  // Epilogue.  C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r.  A row of
+  // four tiles (16 x 64 outputs) goes through the wave's LDS patch and leaves as 16-byte-per-lane
+  // row segments (256 contiguous bytes per 16 lanes) with bias / ReLU / mask applied as float4.
+  float* stage = lds + wave * kStage240;
+  constexpr int kLd = kC240 / kWn240 + 4;
+  const bool wide = (p.rb & 3) == 0 && (p.ldc & 3) == 0;
+  const int c4 = i16 * 4;
+  const int col = n0 + wn * (kC240 / kWn240) + c4;
+  const bool col_ok = col < p.rb;
+  v4f bias = {0.f, 0.f, 0.f, 0.f};
+  if (wide && p.bias != nullptr && col_ok) bias = *reinterpret_cast<const v4f*>(p.bias + col);
+#pragma unroll
+  for (int tm = 0; tm < kTm240; ++tm) {
+    const int row_base = m0 + wm * (kR240 / kWm240) + tm * 16;
+    if (wide) {
+      v4f mk[4];
+      if (p.mask != nullptr) {   // requested first: the latency hides behind the LDS staging
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = row_base + it * 4 + q;
+          mk[it] = (row < row_end && col_ok)
+                       ? *reinterpret_cast<const v4f*>(p.mask + static_cast<size_t>(row) * p.ldc + col)
+                       : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int tn = 0; tn < kTn240; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(4 * q + r) * kLd + tn * 16 + i16] = acc[tm][tn][r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int lrow = it * 4 + q, row = row_base + lrow;
+        v4f val = *reinterpret_cast<const v4f*>(stage + lrow * kLd + c4) + bias;
+        if (row < row_end && col_ok) {
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
+          }
+          if (p.mask != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = mk[it][e] > 0.f ? val[e] : 0.f;
+          }
+          *reinterpret_cast<v4f*>(p.c + static_cast<size_t>(row) * p.ldc + col) = val;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < kTn240; ++tn) {
+        const int c = n0 + wn * (kC240 / kWn240) + tn * 16 + i16;
+        const float bs = (p.bias != nullptr && c < p.rb) ? p.bias[c] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row_base + 4 * q + r;
+          if (row < row_end && c < p.rb) {
+            const size_t off = static_cast<size_t>(row) * p.ldc + c;
+            float val = acc[tm][tn][r] + bs;
+            if (p.relu) val = fmaxf(val, 0.f);
+            if (p.mask != nullptr) val = p.mask[off] > 0.f ? val : 0.f;
+            p.c[off] = val;
+          }
+        }
+      }
+    }
+  }
+  Probe::mark(3);
+}
+
+template <class Probe = NoProbe>
+int launch_rows240(const GemmArgs& p, hipStream_t st) {
+  dim3 grid((p.ra + kR240 - 1) / kR240, (p.rb + kC240 - 1) / kC240, 1);
+  gemm_rows240_kernel<Probe><<<grid, kThreads240, 0, st>>>(p);
+  return launch_status();
 }
 
 // out_q[i] = sum_s slab[q][s][i] for problems q, summed in split order inside four interleaved
@@ -520,27 +710,19 @@ bool skinny_wgrad(const float* g, const float* a, float* gw, float* gb, float* w
 inline bool aligned4(int64_t x) { return (x & 3) == 0; }
 
 // Tile configurations (runtime-selectable for tuning through gts_set_option).
-#ifdef GTS_GEMM_STAMPS
-unsigned long long* g_stamps = nullptr;  // diagnostic build only (tools/diag/gemm_stamps.py)
-int g_diag_flags = 0;
-#endif
 // Defaults from tools/tune_gemm.py at M = 60 000, 256-wide (profiles/r01_tune_gemm.log).
-int g_fwd_variant = -1;    // forward kernels (both operands kk-contiguous); -1 = 8 (double-buffered 256x256, one
-                           // workgroup per CU) when that fills >= 3/4 of the CUs, else 3 (64x256, two per CU);
-                           // in-bench 748-754 graphs/s with 8 vs 738 with 3 (profiles/r01_tune_gemm.log)
+int g_fwd_variant = -1;    // forward kernels (both operands kk-contiguous); -1 = a one-round tile (9 = 240-row
+                           // panels on the 16x16x4 MFMA when they leave fewer rows per CU, else 8 = double-buffered
+                           // 256x256) when that fills >= 3/4 of the CUs, else 3 (64x256, two per CU)
 int g_igrad_variant = 1;   // input-gradient kernels (B kk-strided)
 int g_wgrad_variant = -1;  // split-reduction kernel; -1 = chosen per launch by wgrad_plan()
 
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, bool DB = false>
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, bool DB = false, class Probe = NoProbe>
 int launch_tiles(const GemmArgs& p, int grid_y_mult, int splits, hipStream_t st) {
   GemmArgs q = p;
-#ifdef GTS_GEMM_STAMPS
-  q.stamps = g_stamps;
-  if (g_diag_flags & 1) q.lda[0] = q.lda[1] = 0;  // every row tile reads the same (cache-hot) A rows
-#endif
   q.tiles_n = (p.rb + BN - 1) / BN;
   dim3 grid((p.ra + BM - 1) / BM, q.tiles_n * grid_y_mult, splits);
-  gemm_kernel<BM, BN, WM, WN, AKC, BKC, DB><<<grid, 64 * WM * WN, 0, st>>>(q);
+  gemm_kernel<BM, BN, WM, WN, AKC, BKC, DB, Probe><<<grid, 64 * WM * WN, 0, st>>>(q);
   return launch_status();
 }
 
@@ -550,8 +732,18 @@ int launch_plain(const GemmArgs& p, hipStream_t st) {
   if (p.rb <= 128) return launch_tiles<128, 128, 2, 2, AKC, BKC>(p, 1, 1, st);
   int variant = BKC ? g_fwd_variant : g_igrad_variant;
   if (variant < 0) {
-    const int64_t big_tiles = static_cast<int64_t>((p.ra + 255) / 256) * ((p.rb + 255) / 256);
+    const int64_t cols = (p.rb + 255) / 256;
+    const int64_t big_tiles = static_cast<int64_t>((p.ra + 255) / 256) * cols;
     variant = big_tiles >= 192 ? 8 : 3;
+    if constexpr (AKC && BKC) {
+      // one workgroup per CU, in rounds of 256: rows a CU walks with 256-row tiles vs 240-row panels
+      const int64_t panels = static_cast<int64_t>((p.ra + kR240 - 1) / kR240) * cols;
+      const int64_t rows256 = (big_tiles + 255) / 256 * 256, rows240 = (panels + 255) / 256 * kR240;
+      if (variant == 8 && rows240 < rows256) variant = 9;
+    }
+  }
+  if constexpr (AKC && BKC) {
+    if (variant == 9) return launch_rows240(p, st);
   }
   switch (variant) {
     // the variants that survived the sweeps in profiles/r01_tune_gemm.log (numbers kept from there)
@@ -616,11 +808,6 @@ int launch_wgrad(const GemmArgs& p, const WgradPlan& plan, hipStream_t st) {
 
 }  // namespace
 }  // namespace gts
-
-#ifdef GTS_GEMM_STAMPS
-extern "C" void gts_diag_set_stamps(unsigned long long* buf) { gts::g_stamps = buf; }
-extern "C" void gts_diag_set_flags(int flags) { gts::g_diag_flags = flags; }
-#endif
 
 extern "C" int32_t gts_set_option(int32_t option, int32_t value) {
   switch (option) {

@@ -70,19 +70,80 @@ def test_linear_forward_one_round_tile(m, k, n, dual):
 
 @pytest.mark.parametrize("m,f,dual", [(60000, 256, True), (49999, 1024, False)])
 def test_forward_tile_variants_are_bitwise_identical_at_full_size(hip_lib, m, f, dual):
-    """Every tile variant walks the reduction in the same order, so the C2- / C3-sized forward
-    GEMM of the one-round 256x256 tile (default there) equals the 64x256 tile the small-graph
-    parity tests exercise, bit for bit."""
+    """Every 32x32x2 tile variant walks the reduction in the same order, so the C2- / C3-sized forward
+    GEMM of the one-round 256x256 tile equals the 64x256 / 128x256 tiles the small-graph parity tests
+    exercise, bit for bit.  The 240-row panels (variant 9, what -1 selects at these sizes) run on the
+    16x16x4 MFMA, which adds four products per step instead of two: equal to fp32 rounding (checked
+    against fp64 in the tests below), deterministic, and what the automatic choice returns."""
     a0, w0, b = _rand(m, f, seed=21).to(DEV), _rand(f, f, seed=23).to(DEV), _rand(f, seed=25).to(DEV)
     a1, w1 = (_rand(m, f, seed=22).to(DEV), _rand(f, f, seed=24).to(DEV)) if dual else (None, None)
-    outs = []
+    outs = {}
     try:
-        for variant in (-1, 8, 3, 1):
+        for variant in (8, 3, 1, 9, -1, 9):
             assert hip_lib.gts_set_option(1, variant) == 0
-            outs.append(dense.linear_fwd(a0, w0, a1, w1, bias=b, relu=True))
+            outs.setdefault(variant, []).append(dense.linear_fwd(a0, w0, a1, w1, bias=b, relu=True))
     finally:
         hip_lib.gts_set_option(1, -1)
-    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert torch.equal(outs[8][0], outs[3][0]) and torch.equal(outs[8][0], outs[1][0])
+    assert torch.equal(outs[9][0], outs[9][1]) and torch.equal(outs[9][0], outs[-1][0])
+    scale = float(outs[8][0].abs().max())
+    assert float((outs[9][0] - outs[8][0]).abs().max()) < 1e-5 * scale
+
+
+ROWS240 = [(240, 256, 256, 0), (239, 64, 256, 64), (241, 32, 260, 0), (1000, 132, 132, 260), (60000, 256, 256, 256),
+           (49999, 260, 1024, 0), (481, 4, 8, 4), (5, 36, 4, 0), (120000, 256, 256, 0)]
+
+
+@pytest.mark.parametrize("m,k0,n,k1", ROWS240)
+@pytest.mark.parametrize("relu,bias,mask", [(True, True, False), (False, False, True)])
+def test_rows240_panels_against_fp64(hip_lib, m, k0, n, k1, relu, bias, mask):
+    """gemm_rows240_kernel (v_mfma_f32_16x16x4_f32, 240 x 256 panels) forced on every shape class:
+    ragged panels / columns / reduction tiles, both segments, bias + ReLU, and the ReLU-mask epilogue
+    of the transposed-weight input gradient."""
+    a0, w0 = _rand(m, k0, seed=1), _rand(n, k0, seed=2)
+    a1, w1 = (_rand(m, k1, seed=3), _rand(n, k1, seed=4)) if k1 else (None, None)
+    b = _rand(n, seed=5) if bias else None
+    rm = _rand(m, n, seed=6) if mask else None
+    want = a0.double() @ w0.double().t()
+    bound = a0.double().abs() @ w0.double().abs().t()
+    if k1:
+        want += a1.double() @ w1.double().t()
+        bound += a1.double().abs() @ w1.double().abs().t()
+    if bias:
+        want += b.double()
+        bound += b.double().abs()
+    if relu:
+        want = want.clamp(min=0)
+    if mask:
+        want = want * (rm > 0)
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    try:
+        assert hip_lib.gts_set_option(1, 9) == 0
+        if mask:     # the mask lives on the input-gradient entry point: gin = g @ W from W^T (here w = W^T)
+            got = dense.linear_bwd_input_t(dev(a0), dev(w0), dev(a1), dev(w1), relu_mask=dev(rm))
+        else:
+            got = dense.linear_fwd(dev(a0), dev(w0), dev(a1), dev(w1), bias=dev(b), relu=relu)
+        again = dense.linear_fwd(dev(a0), dev(w0), dev(a1), dev(w1), bias=dev(b), relu=relu) if not mask else got
+    finally:
+        hip_lib.gts_set_option(1, -1)
+    assert got.shape == (m, n) and torch.equal(got, again)
+    _check(got, want, bound)
+
+
+def test_rows240_narrow_output_through_the_c_abi(hip_lib):
+    """n not a multiple of 4 (only reachable through the C ABI; the Python layer pads): scalar stores."""
+    from gts._lib import current_stream, ptr
+
+    m, k, n = 500, 64, 6
+    a, w, b = _rand(m, k, seed=1).to(DEV), _rand(n, k, seed=2).to(DEV), _rand(n, seed=3).to(DEV)
+    out = torch.full((m, n), float("nan"), device=DEV)
+    try:
+        assert hip_lib.gts_set_option(1, 9) == 0
+        assert hip_lib.gts_linear_fwd_f32(ptr(a), ptr(w), None, None, ptr(b), ptr(out), m, n, k, 0, 1, current_stream()) == 0
+    finally:
+        hip_lib.gts_set_option(1, -1)
+    want = (a.cpu().double() @ w.cpu().double().t() + b.cpu().double()).clamp(min=0)
+    assert torch.allclose(out.cpu().double(), want, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("m,k,n", SHAPES)
@@ -166,16 +227,22 @@ def test_transpose_batch(rows, cols, count):
 @pytest.mark.parametrize("m,k,n0,n1,mask", [(60000, 256, 256, 256, True), (60000, 256, 256, 0, False),
                                             (49999, 132, 260, 64, True), (300, 256, 4, 256, False),
                                             (120000, 256, 256, 256, True)])
-def test_input_gradient_from_transposed_weights_is_bitwise_the_strided_form(m, k, n0, n1, mask):
-    """gts_linear_bwd_input_t_f32 (forward-form kernel on W^T) against gts_linear_bwd_input_f32 and fp64."""
+def test_input_gradient_from_transposed_weights(m, k, n0, n1, mask):
+    """gts_linear_bwd_input_t_f32 (forward-form kernel on W^T) against gts_linear_bwd_input_f32 (bitwise on the
+    same MFMA shape) and fp64."""
     g0, w0 = _rand(m, n0, seed=1).to(DEV), _rand(n0, k, seed=2).to(DEV)
     g1, w1 = (_rand(m, n1, seed=3).to(DEV), _rand(n1, k, seed=4).to(DEV)) if n1 else (None, None)
     rm = _rand(m, k, seed=5).to(DEV) if mask else None
     want = dense.linear_bwd_input(g0, w0, g1, w1, relu_mask=rm)
     w0t = dense.transpose_batch([w0])[0]
     w1t = dense.transpose_batch([w1])[0] if n1 else None
-    got = dense.linear_bwd_input_t(g0, w0t, g1, w1t, relu_mask=rm)
-    assert torch.equal(got, want)
+    lib = dense._lib.load()
+    try:          # same 32x32x2 reduction order as the strided kernel when the 256x256 tile is forced
+        assert lib.gts_set_option(1, 8) == 0
+        assert torch.equal(dense.linear_bwd_input_t(g0, w0t, g1, w1t, relu_mask=rm), want)
+    finally:
+        lib.gts_set_option(1, -1)
+    got = dense.linear_bwd_input_t(g0, w0t, g1, w1t, relu_mask=rm)       # automatic tile (240-row panels when large)
     ref = g0.cpu().double() @ w0.cpu().double()
     bound = g0.cpu().double().abs() @ w0.cpu().double().abs()
     if n1:

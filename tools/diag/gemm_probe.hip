@@ -1,0 +1,53 @@
+// Diagnostic translation unit (never part of libgts_hip.so): the K11 kernels of
+// gnn-tumor-seg_amd/csrc/gts_gemm.hip instantiated with a probe that records, per workgroup and
+// phase (0 start, 1 operands staged, 2 main loop done, 3 tile stored), the constant 100 MHz
+// s_memrealtime counter and the shader-clock s_memtime counter (their ratio = in-kernel clock).
+// Built and driven by tools/diag/gemm_stamps.py.
+#include "../../gnn-tumor-seg_amd/csrc/gts_gemm.hip"
+
+namespace gts {
+namespace {
+
+__device__ unsigned long long* g_probe = nullptr;  // [workgroup][phase][2]
+
+struct StampProbe {
+  __device__ __forceinline__ static void mark(int phase) {
+    if (phase == 3) __syncthreads();
+    if (threadIdx.x == 0 && g_probe != nullptr) {
+      const size_t at = ((static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4 + phase) * 2;
+      g_probe[at] = __builtin_amdgcn_s_memrealtime();
+      g_probe[at + 1] = __builtin_amdgcn_s_memtime();
+    }
+  }
+};
+
+}  // namespace
+}  // namespace gts
+
+extern "C" int gts_probe_set_buffer(unsigned long long* buf) {
+  return static_cast<int>(hipMemcpyToSymbol(HIP_SYMBOL(gts::g_probe), &buf, sizeof(buf)));
+}
+
+// forward GEMM of the library with the stamping kernels; variant as GTS_OPT_GEMM_TILE;
+// a_hot != 0: every row tile reads the same (cache-hot) A rows (row stride 0)
+extern "C" int gts_probe_linear_fwd(const float* a0, const float* w0, const float* a1, const float* w1,
+                                    const float* bias, float* out, int64_t m, int64_t n, int64_t k0,
+                                    int64_t k1, int32_t relu, int32_t variant, int32_t a_hot,
+                                    void* stream) {
+  using namespace gts;
+  GemmArgs p{};
+  p.a[0] = a0, p.b[0] = w0, p.lda[0] = static_cast<int>(k0), p.ldb[0] = static_cast<int>(k0);
+  p.kseg[0] = static_cast<int>(k0);
+  p.a[1] = a1 ? a1 : a0, p.b[1] = w1 ? w1 : w0;
+  p.lda[1] = p.ldb[1] = static_cast<int>(k1), p.kseg[1] = a1 ? static_cast<int>(k1) : 0;
+  p.ra = static_cast<int>(m), p.rb = static_cast<int>(n), p.c = out, p.ldc = static_cast<int>(n);
+  p.bias = bias, p.relu = relu;
+  p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
+  if (a_hot) p.lda[0] = p.lda[1] = 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (variant) {
+    case 3: return launch_tiles<64, 256, 2, 4, true, true, false, StampProbe>(p, 1, 1, st);
+    case 8: return launch_tiles<256, 256, 4, 4, true, true, true, StampProbe>(p, 1, 1, st);
+    default: return launch_tiles<128, 256, 2, 4, true, true, false, StampProbe>(p, 1, 1, st);
+  }
+}
