@@ -35,6 +35,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kBK = 32;         // reduction elements per LDS tile
 constexpr int kKcLd = kBK + 4;  // padded row of a kk-contiguous LDS image
 constexpr int kMaxProblems = 32;
+int g_gemm_sched = 0;           // GemmArgs::sched (GTS_OPT_GEMM_SCHED)
 
 struct GemmArgs {
   const float* a[2];    // forward / input grad: the two (a, b) reduction segments
@@ -55,6 +56,7 @@ struct GemmArgs {
   int tiles_n;          // output tiles along rb per problem
   int n_splits;
   int tiles_per_split;  // reduction tiles handled by one blockIdx.z
+  int sched;            // tuning bits (GTS_OPT_GEMM_SCHED): 1 = waves further into a tile yield MFMA issue
 };
 
 // Phase probe of the kernel (start / operands staged / main loop done / tile stored).  The
@@ -270,6 +272,12 @@ void gemm_kernel(const GemmArgs p) {
   auto compute = [&]() {
 #pragma unroll
     for (int g = 0; g < kBK / 8; ++g) {
+      if (DB && (p.sched & 1)) {   // the builtin wants a literal
+        if (g == 0) __builtin_amdgcn_s_setprio(3);
+        else if (g == 1) __builtin_amdgcn_s_setprio(2);
+        else if (g == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
       float af[TM][4], bf[TN][4];
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) TA::fragment(af[tm], lds_a, wm * WTM + tm * 32, g);
@@ -433,6 +441,10 @@ __global__ __launch_bounds__(kThreads240, kWm240 * kWn240 / 4) void gemm_rows240
     const float* lb = lds + image * kImage + kAFloats + (wn * (kC240 / kWn240) + i16) * kKcLd + 4 * q;
 #pragma unroll
     for (int g = 0; g < kBK / 16; ++g) {
+      if (p.sched & 1) {
+        if (g == 0) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
+      }
       v4f af[kTm240];
 #pragma unroll
       for (int tm = 0; tm < kTm240; ++tm) af[tm] = *reinterpret_cast<const v4f*>(la + tm * 16 * kKcLd + g * 16);
@@ -540,7 +552,187 @@ __global__ __launch_bounds__(kThreads240, kWm240 * kWn240 / 4) void gemm_rows240
 template <class Probe = NoProbe>
 int launch_rows240(const GemmArgs& p, hipStream_t st) {
   dim3 grid((p.ra + kR240 - 1) / kR240, (p.rb + kC240 - 1) / kC240, 1);
-  gemm_rows240_kernel<Probe><<<grid, kThreads240, 0, st>>>(p);
+  GemmArgs q = p;
+  q.sched = g_gemm_sched;
+  gemm_rows240_kernel<Probe><<<grid, kThreads240, 0, st>>>(q);
+  return launch_status();
+}
+
+// ---- 240-row panels, operands straight into MFMA fragments (no LDS staging, no barriers) --------
+// Same decomposition as gemm_rows240_kernel (12 waves, one wave = 80 x 64 outputs on the 16x16x4
+// MFMA), but a lane fetches its own fragments from global memory: lane (i, q) of a wave needs
+// A[row i][16 g + 4 q .. + 3] — one 16-byte load — and the 16 lanes of a quarter cover 16 rows x
+// 64 contiguous bytes.  Each A row is fetched by the four waves that share it and each weight row by
+// three (L1 / L2 hits: per CU and 32-deep reduction step 221 KB instead of 62 KB, 34 GB/s per CU),
+// which buys: no LDS images, no stash, no barrier — the twelve waves of a workgroup are
+// independent instruction streams that drift apart, so one wave's wait for memory is another
+// wave's MFMA time, and the store burst of the epilogue spreads out the same way.  Two register
+// sets of fragments: the loads of reduction group g+1 are in flight under the 80 MFMAs of group g.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+constexpr unsigned kOutOfRange = 0x7FFFFFF0u;   // byte offset no operand panel reaches: the load returns 0
+
+// nine 16-byte buffer loads: address = panel base (SGPR resource) + lane offset (one VGPR per
+// fragment row block) + reduction offset (SGPR); offsets past the panel's bytes read as 0
+__device__ __forceinline__ void load_fragments(v4f (&af)[kTm240], v4f (&bf)[kTn240], __amdgpu_buffer_rsrc_t ra,
+                                               __amdgpu_buffer_rsrc_t rb, const unsigned (&off_a)[kTm240],
+                                               const unsigned (&off_b)[kTn240], int k_bytes) {
+#pragma unroll
+  for (int tm = 0; tm < kTm240; ++tm)
+    af[tm] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ra, off_a[tm], k_bytes, 0));
+#pragma unroll
+  for (int tn = 0; tn < kTn240; ++tn)
+    bf[tn] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rb, off_b[tn], k_bytes, 0));
+}
+
+__device__ __forceinline__ void mfma_group(v4acc (&acc)[kTm240][kTn240], const v4f (&af)[kTm240],
+                                           const v4f (&bf)[kTn240]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int tm = 0; tm < kTm240; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < kTn240; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tm][j], bf[tn][j], acc[tm][tn], 0, 0, 0);
+}
+
+template <class Probe = NoProbe>
+__global__ __launch_bounds__(kThreads240, kWm240 * kWn240 / 4) void gemm_rows240_direct_kernel(const GemmArgs p) {
+  __shared__ float lds[kWm240 * kWn240 * kStage240];   // epilogue patches only
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / kWn240, wn = wave % kWn240;
+  const int i16 = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.x * kR240, n0 = blockIdx.y * kC240;
+  const int row_end = min(p.ra, m0 + kR240);
+
+  v4acc acc[kTm240][kTn240];
+#pragma unroll
+  for (int tm = 0; tm < kTm240; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < kTn240; ++tn) acc[tm][tn] = v4acc{0.f, 0.f, 0.f, 0.f};
+
+  Probe::mark(0);
+  Probe::mark(1);
+#pragma unroll
+  for (int seg = 0; seg < 2; ++seg) {
+    const int kseg = p.kseg[seg];
+    if (kseg == 0) continue;
+    const int lda = p.lda[seg], ldb = p.ldb[seg];
+    // buffer resources over this workgroup's operand panels: rows [m0, row_end) of A, weight rows
+    // [n0, n0 + 256) — anything past their last byte reads as 0 (no row clamps, no branches)
+    const int cols = min(p.rb - n0, kC240);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.a[seg] + static_cast<size_t>(m0) * lda), 0, (row_end - m0) * lda * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.b[seg] + static_cast<size_t>(n0) * ldb), 0, cols * ldb * 4, 0x00020000);
+    unsigned off_a[kTm240], off_b[kTn240];
+#pragma unroll
+    for (int tm = 0; tm < kTm240; ++tm)
+      off_a[tm] = (static_cast<unsigned>(wm * (kR240 / kWm240) + tm * 16 + i16) * lda + 4 * q) * 4;
+#pragma unroll
+    for (int tn = 0; tn < kTn240; ++tn)
+      off_b[tn] = (static_cast<unsigned>(wn * (kC240 / kWn240) + tn * 16 + i16) * ldb + 4 * q) * 4;
+    const int n_full = kseg / 16, tail = kseg % 16;
+    v4f af0[kTm240], bf0[kTn240], af1[kTm240], bf1[kTn240];
+    int g = 0;
+    if (n_full > 0) load_fragments(af0, bf0, ra, rb, off_a, off_b, 0);
+    for (; g + 2 <= n_full; g += 2) {
+      load_fragments(af1, bf1, ra, rb, off_a, off_b, 64 * (g + 1));
+      mfma_group(acc, af0, bf0);
+      load_fragments(af0, bf0, ra, rb, off_a, off_b, 64 * min(g + 2, n_full - 1));  // last: harmless re-read
+      mfma_group(acc, af1, bf1);
+      // pin the software pipeline: the nine loads of a group are issued before the 80 MFMAs of the
+      // group in front of it (left alone, the scheduler sinks them to save registers and the wave
+      // then waits for each one right after issuing it)
+      __builtin_amdgcn_sched_group_barrier(0x020, kTm240 + kTn240, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * kTm240 * kTn240, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, kTm240 + kTn240, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * kTm240 * kTn240, 0);
+    }
+    if (g < n_full) mfma_group(acc, af0, bf0);
+    if (tail != 0) {   // kseg is a multiple of 4: quarter q lies inside the tail or past the row's end
+      if (4 * q >= tail) {
+#pragma unroll
+        for (int tm = 0; tm < kTm240; ++tm) off_a[tm] = kOutOfRange;
+#pragma unroll
+        for (int tn = 0; tn < kTn240; ++tn) off_b[tn] = kOutOfRange;
+      }
+      load_fragments(af1, bf1, ra, rb, off_a, off_b, 64 * n_full);
+      mfma_group(acc, af1, bf1);
+    }
+  }
+  Probe::mark(2);
+
+  float* stage = lds + wave * kStage240;
+  constexpr int kLd = kC240 / kWn240 + 4;
+  const bool wide = (p.rb & 3) == 0 && (p.ldc & 3) == 0;
+  const int c4 = i16 * 4;
+  const int col = n0 + wn * (kC240 / kWn240) + c4;
+  const bool col_ok = col < p.rb;
+  v4f bias = {0.f, 0.f, 0.f, 0.f};
+  if (wide && p.bias != nullptr && col_ok) bias = *reinterpret_cast<const v4f*>(p.bias + col);
+#pragma unroll
+  for (int tm = 0; tm < kTm240; ++tm) {
+    const int row_base = m0 + wm * (kR240 / kWm240) + tm * 16;
+    if (wide) {
+      v4f mk[4];
+      if (p.mask != nullptr) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = row_base + it * 4 + q;
+          mk[it] = (row < row_end && col_ok)
+                       ? *reinterpret_cast<const v4f*>(p.mask + static_cast<size_t>(row) * p.ldc + col)
+                       : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int tn = 0; tn < kTn240; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(4 * q + r) * kLd + tn * 16 + i16] = acc[tm][tn][r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int lrow = it * 4 + q, row = row_base + lrow;
+        v4f val = *reinterpret_cast<const v4f*>(stage + lrow * kLd + c4) + bias;
+        if (row < row_end && col_ok) {
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
+          }
+          if (p.mask != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = mk[it][e] > 0.f ? val[e] : 0.f;
+          }
+          *reinterpret_cast<v4f*>(p.c + static_cast<size_t>(row) * p.ldc + col) = val;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < kTn240; ++tn) {
+        const int c = n0 + wn * (kC240 / kWn240) + tn * 16 + i16;
+        const float bs = (p.bias != nullptr && c < p.rb) ? p.bias[c] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row_base + 4 * q + r;
+          if (row < row_end && c < p.rb) {
+            const size_t off = static_cast<size_t>(row) * p.ldc + c;
+            float val = acc[tm][tn][r] + bs;
+            if (p.relu) val = fmaxf(val, 0.f);
+            if (p.mask != nullptr) val = p.mask[off] > 0.f ? val : 0.f;
+            p.c[off] = val;
+          }
+        }
+      }
+    }
+  }
+  Probe::mark(3);
+}
+
+template <class Probe = NoProbe>
+int launch_rows240_direct(const GemmArgs& p, hipStream_t st) {
+  dim3 grid((p.ra + kR240 - 1) / kR240, (p.rb + kC240 - 1) / kC240, 1);
+  gemm_rows240_direct_kernel<Probe><<<grid, kThreads240, 0, st>>>(p);
   return launch_status();
 }
 
@@ -720,6 +912,7 @@ int g_wgrad_variant = -1;  // split-reduction kernel; -1 = chosen per launch by 
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, bool DB = false, class Probe = NoProbe>
 int launch_tiles(const GemmArgs& p, int grid_y_mult, int splits, hipStream_t st) {
   GemmArgs q = p;
+  q.sched = g_gemm_sched;
   q.tiles_n = (p.rb + BN - 1) / BN;
   dim3 grid((p.ra + BM - 1) / BM, q.tiles_n * grid_y_mult, splits);
   gemm_kernel<BM, BN, WM, WN, AKC, BKC, DB, Probe><<<grid, 64 * WM * WN, 0, st>>>(q);
@@ -744,6 +937,7 @@ int launch_plain(const GemmArgs& p, hipStream_t st) {
   }
   if constexpr (AKC && BKC) {
     if (variant == 9) return launch_rows240(p, st);
+    if (variant == 10) return launch_rows240_direct(p, st);
   }
   switch (variant) {
     // the variants that survived the sweeps in profiles/r01_tune_gemm.log (numbers kept from there)
@@ -817,6 +1011,7 @@ extern "C" int32_t gts_set_option(int32_t option, int32_t value) {
     case GTS_OPT_SPMM_STREAMING: gts::g_spmm_nt = value; return GTS_OK;
     case GTS_OPT_PROJECT_STREAMING: gts::g_project_nt = value; return GTS_OK;
     case GTS_OPT_WGRAD_TILE: gts::g_wgrad_variant = value; return GTS_OK;
+    case GTS_OPT_GEMM_SCHED: gts::g_gemm_sched = value; return GTS_OK;
     default: return GTS_ERR_ARGKIND;
   }
 }

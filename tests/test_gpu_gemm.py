@@ -94,10 +94,12 @@ ROWS240 = [(240, 256, 256, 0), (239, 64, 256, 64), (241, 32, 260, 0), (1000, 132
            (49999, 260, 1024, 0), (481, 4, 8, 4), (5, 36, 4, 0), (120000, 256, 256, 0)]
 
 
+@pytest.mark.parametrize("variant", [9, 10])
 @pytest.mark.parametrize("m,k0,n,k1", ROWS240)
 @pytest.mark.parametrize("relu,bias,mask", [(True, True, False), (False, False, True)])
-def test_rows240_panels_against_fp64(hip_lib, m, k0, n, k1, relu, bias, mask):
-    """gemm_rows240_kernel (v_mfma_f32_16x16x4_f32, 240 x 256 panels) forced on every shape class:
+def test_rows240_panels_against_fp64(hip_lib, m, k0, n, k1, relu, bias, mask, variant):
+    """The 240 x 256 panel kernels on v_mfma_f32_16x16x4_f32 (9 = operands staged through LDS, 10 = operands
+    loaded straight into the MFMA fragments through buffer loads) forced on every shape class:
     ragged panels / columns / reduction tiles, both segments, bias + ReLU, and the ReLU-mask epilogue
     of the transposed-weight input gradient."""
     a0, w0 = _rand(m, k0, seed=1), _rand(n, k0, seed=2)
@@ -118,7 +120,7 @@ def test_rows240_panels_against_fp64(hip_lib, m, k0, n, k1, relu, bias, mask):
         want = want * (rm > 0)
     dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
     try:
-        assert hip_lib.gts_set_option(1, 9) == 0
+        assert hip_lib.gts_set_option(1, variant) == 0
         if mask:     # the mask lives on the input-gradient entry point: gin = g @ W from W^T (here w = W^T)
             got = dense.linear_bwd_input_t(dev(a0), dev(w0), dev(a1), dev(w1), relu_mask=dev(rm))
         else:
