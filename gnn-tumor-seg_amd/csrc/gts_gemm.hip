@@ -559,57 +559,66 @@ int launch_rows240(const GemmArgs& p, hipStream_t st) {
 }
 
 // ---- 240-row panels, operands straight into MFMA fragments (no LDS staging, no barriers) --------
-// Same decomposition as gemm_rows240_kernel (12 waves, one wave = 80 x 64 outputs on the 16x16x4
-// MFMA), but a lane fetches its own fragments from global memory: lane (i, q) of a wave needs
-// A[row i][16 g + 4 q .. + 3] — one 16-byte load — and the 16 lanes of a quarter cover 16 rows x
-// 64 contiguous bytes.  Each A row is fetched by the four waves that share it and each weight row by
-// three (L1 / L2 hits: per CU and 32-deep reduction step 221 KB instead of 62 KB, 34 GB/s per CU),
-// which buys: no LDS images, no stash, no barrier — the twelve waves of a workgroup are
-// independent instruction streams that drift apart, so one wave's wait for memory is another
-// wave's MFMA time, and the store burst of the epilogue spreads out the same way.  Two register
-// sets of fragments: the loads of reduction group g+1 are in flight under the 80 MFMAs of group g.
+// Same panels as gemm_rows240_kernel (240 x 256 outputs per workgroup on the 16x16x4 MFMA), but a
+// lane fetches its own fragments from global memory: lane (i, q) of a wave needs
+// A[row i][16 g + 4 q .. + 3] — one 16-byte buffer load — and the 16 lanes of a quarter cover 16
+// rows x 64 contiguous bytes.  No LDS images, no stash, no barrier: the waves of a workgroup are
+// independent instruction streams, one wave's wait for memory is another wave's MFMA time, and
+// the store burst of the epilogue spreads out the same way.  DEPTH + 1 register sets of fragments:
+// the loads of reduction groups g+1 .. g+DEPTH are in flight under the MFMAs of group g.
+//   WM x WN = 3 x 4: twelve waves of 80 x 64 outputs (3 per SIMD, 80 accumulator registers); every
+//             A row is fetched by four waves and every weight row by three (L1 / L2 hits, but
+//             42 B/clk of L1 traffic per CU);
+//   WM x WN = 1 x 4: four waves of 240 x 64 outputs, ONE per SIMD with 240 accumulator registers and
+//             the whole 512-register file: every A element is fetched exactly once per workgroup,
+//             10 B/clk of L1 traffic, and a group of 240 MFMAs (3.2 us) covers the next loads.
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr unsigned kOutOfRange = 0x7FFFFFF0u;   // byte offset no operand panel reaches: the load returns 0
 
-// nine 16-byte buffer loads: address = panel base (SGPR resource) + lane offset (one VGPR per
+// TM + TN 16-byte buffer loads: address = panel base (SGPR resource) + lane offset (one VGPR per
 // fragment row block) + reduction offset (SGPR); offsets past the panel's bytes read as 0
-__device__ __forceinline__ void load_fragments(v4f (&af)[kTm240], v4f (&bf)[kTn240], __amdgpu_buffer_rsrc_t ra,
-                                               __amdgpu_buffer_rsrc_t rb, const unsigned (&off_a)[kTm240],
-                                               const unsigned (&off_b)[kTn240], int k_bytes) {
+template <int TM, int TN>
+__device__ __forceinline__ void load_fragments(v4f (&af)[TM], v4f (&bf)[TN], __amdgpu_buffer_rsrc_t ra,
+                                               __amdgpu_buffer_rsrc_t rb, const unsigned (&off_a)[TM],
+                                               const unsigned (&off_b)[TN], int k_bytes) {
 #pragma unroll
-  for (int tm = 0; tm < kTm240; ++tm)
+  for (int tm = 0; tm < TM; ++tm)
     af[tm] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ra, off_a[tm], k_bytes, 0));
 #pragma unroll
-  for (int tn = 0; tn < kTn240; ++tn)
+  for (int tn = 0; tn < TN; ++tn)
     bf[tn] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rb, off_b[tn], k_bytes, 0));
 }
 
-__device__ __forceinline__ void mfma_group(v4acc (&acc)[kTm240][kTn240], const v4f (&af)[kTm240],
-                                           const v4f (&bf)[kTn240]) {
+template <int TM, int TN>
+__device__ __forceinline__ void mfma_group(v4acc (&acc)[TM][TN], const v4f (&af)[TM], const v4f (&bf)[TN]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int tm = 0; tm < kTm240; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < kTn240; ++tn)
+      for (int tn = 0; tn < TN; ++tn)
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tm][j], bf[tn][j], acc[tm][tn], 0, 0, 0);
 }
 
-template <class Probe = NoProbe>
-__global__ __launch_bounds__(kThreads240, kWm240 * kWn240 / 4) void gemm_rows240_direct_kernel(const GemmArgs p) {
-  __shared__ float lds[kWm240 * kWn240 * kStage240];   // epilogue patches only
+template <int WM, int WN, int DEPTH, class Probe = NoProbe>
+__global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_kernel(const GemmArgs p) {
+  constexpr int WTM = kR240 / WM, WTN = kC240 / WN, TM = WTM / 16, TN = WTN / 16;
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0 && WTN % 4 == 0 && (WM * WN) % 4 == 0, "wave tiles are whole 16x16 tiles");
+  constexpr int R = DEPTH + 1;                     // register sets of fragments
+  constexpr int kLd = WTN + 4, kStage = 16 * kLd;  // per-wave epilogue patch [16][WTN + 4]
+  __shared__ float lds[WM * WN * kStage];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave / kWn240, wn = wave % kWn240;
+  const int wm = wave / WN, wn = wave % WN;
   const int i16 = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.x * kR240, n0 = blockIdx.y * kC240;
   const int row_end = min(p.ra, m0 + kR240);
 
-  v4acc acc[kTm240][kTn240];
+  v4acc acc[TM][TN];
 #pragma unroll
-  for (int tm = 0; tm < kTm240; ++tm)
+  for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < kTn240; ++tn) acc[tm][tn] = v4acc{0.f, 0.f, 0.f, 0.f};
+    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = v4acc{0.f, 0.f, 0.f, 0.f};
 
   Probe::mark(0);
   Probe::mark(1);
@@ -625,74 +634,87 @@ __global__ __launch_bounds__(kThreads240, kWm240 * kWn240 / 4) void gemm_rows240
         const_cast<float*>(p.a[seg] + static_cast<size_t>(m0) * lda), 0, (row_end - m0) * lda * 4, 0x00020000);
     __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.b[seg] + static_cast<size_t>(n0) * ldb), 0, cols * ldb * 4, 0x00020000);
-    unsigned off_a[kTm240], off_b[kTn240];
+    unsigned off_a[TM], off_b[TN];
 #pragma unroll
-    for (int tm = 0; tm < kTm240; ++tm)
-      off_a[tm] = (static_cast<unsigned>(wm * (kR240 / kWm240) + tm * 16 + i16) * lda + 4 * q) * 4;
+    for (int tm = 0; tm < TM; ++tm) off_a[tm] = (static_cast<unsigned>(wm * WTM + tm * 16 + i16) * lda + 4 * q) * 4;
 #pragma unroll
-    for (int tn = 0; tn < kTn240; ++tn)
-      off_b[tn] = (static_cast<unsigned>(wn * (kC240 / kWn240) + tn * 16 + i16) * ldb + 4 * q) * 4;
+    for (int tn = 0; tn < TN; ++tn) off_b[tn] = (static_cast<unsigned>(wn * WTN + tn * 16 + i16) * ldb + 4 * q) * 4;
     const int n_full = kseg / 16, tail = kseg % 16;
-    v4f af0[kTm240], bf0[kTn240], af1[kTm240], bf1[kTn240];
+    v4f af[R][TM], bf[R][TN];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u)     // groups 0 .. DEPTH-1 (clamped: re-reads are harmless)
+      if (n_full > 0) load_fragments(af[u], bf[u], ra, rb, off_a, off_b, 64 * min(u, n_full - 1));
     int g = 0;
-    if (n_full > 0) load_fragments(af0, bf0, ra, rb, off_a, off_b, 0);
-    for (; g + 2 <= n_full; g += 2) {
-      load_fragments(af1, bf1, ra, rb, off_a, off_b, 64 * (g + 1));
-      mfma_group(acc, af0, bf0);
-      load_fragments(af0, bf0, ra, rb, off_a, off_b, 64 * min(g + 2, n_full - 1));  // last: harmless re-read
-      mfma_group(acc, af1, bf1);
-      // pin the software pipeline: the nine loads of a group are issued before the 80 MFMAs of the
-      // group in front of it (left alone, the scheduler sinks them to save registers and the wave
-      // then waits for each one right after issuing it)
-      __builtin_amdgcn_sched_group_barrier(0x020, kTm240 + kTn240, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * kTm240 * kTn240, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, kTm240 + kTn240, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * kTm240 * kTn240, 0);
+    for (; g + R <= n_full; g += R) {
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        load_fragments(af[(u + DEPTH) % R], bf[(u + DEPTH) % R], ra, rb, off_a, off_b,
+                       64 * min(g + u + DEPTH, n_full - 1));
+        mfma_group(acc, af[u], bf[u]);
+      }
+      // pin the software pipeline: the loads of a group are issued before the MFMAs of the group
+      // DEPTH in front of it (left alone, the scheduler sinks them to save registers and the wave
+      // then waits for each load right after issuing it)
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        __builtin_amdgcn_sched_group_barrier(0x020, TM + TN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+      }
     }
-    if (g < n_full) mfma_group(acc, af0, bf0);
+#pragma unroll
+    for (int u = 0; u < R - 1; ++u) {   // the last n_full % R groups: their fragments are already on the way
+      if (g + u < n_full) {
+        if (g + u + DEPTH < n_full)
+          load_fragments(af[(u + DEPTH) % R], bf[(u + DEPTH) % R], ra, rb, off_a, off_b, 64 * (g + u + DEPTH));
+        mfma_group(acc, af[u], bf[u]);
+      }
+    }
     if (tail != 0) {   // kseg is a multiple of 4: quarter q lies inside the tail or past the row's end
       if (4 * q >= tail) {
 #pragma unroll
-        for (int tm = 0; tm < kTm240; ++tm) off_a[tm] = kOutOfRange;
+        for (int tm = 0; tm < TM; ++tm) off_a[tm] = kOutOfRange;
 #pragma unroll
-        for (int tn = 0; tn < kTn240; ++tn) off_b[tn] = kOutOfRange;
+        for (int tn = 0; tn < TN; ++tn) off_b[tn] = kOutOfRange;
       }
-      load_fragments(af1, bf1, ra, rb, off_a, off_b, 64 * n_full);
-      mfma_group(acc, af1, bf1);
+      load_fragments(af[0], bf[0], ra, rb, off_a, off_b, 64 * n_full);
+      mfma_group(acc, af[0], bf[0]);
     }
   }
   Probe::mark(2);
 
-  float* stage = lds + wave * kStage240;
-  constexpr int kLd = kC240 / kWn240 + 4;
+  // Epilogue as in gemm_rows240_kernel: a row of TN tiles (16 x WTN outputs) through the wave's LDS
+  // patch, out as 16-byte row segments with bias / ReLU / mask applied as float4.
+  float* stage = lds + wave * kStage;
   const bool wide = (p.rb & 3) == 0 && (p.ldc & 3) == 0;
-  const int c4 = i16 * 4;
-  const int col = n0 + wn * (kC240 / kWn240) + c4;
+  constexpr int kC4 = WTN / 4;                // float4 per patch row
+  constexpr int kRowsPerIt = 64 / kC4;        // patch rows one pass of the wave covers
+  const int c4 = (lane % kC4) * 4, rsub = lane / kC4;
+  const int col = n0 + wn * WTN + c4;
   const bool col_ok = col < p.rb;
   v4f bias = {0.f, 0.f, 0.f, 0.f};
   if (wide && p.bias != nullptr && col_ok) bias = *reinterpret_cast<const v4f*>(p.bias + col);
 #pragma unroll
-  for (int tm = 0; tm < kTm240; ++tm) {
-    const int row_base = m0 + wm * (kR240 / kWm240) + tm * 16;
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row_base = m0 + wm * WTM + tm * 16;
     if (wide) {
-      v4f mk[4];
+      v4f mk[16 / kRowsPerIt];
       if (p.mask != nullptr) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int row = row_base + it * 4 + q;
+        for (int it = 0; it < 16 / kRowsPerIt; ++it) {
+          const int row = row_base + it * kRowsPerIt + rsub;
           mk[it] = (row < row_end && col_ok)
                        ? *reinterpret_cast<const v4f*>(p.mask + static_cast<size_t>(row) * p.ldc + col)
                        : v4f{0.f, 0.f, 0.f, 0.f};
         }
       }
 #pragma unroll
-      for (int tn = 0; tn < kTn240; ++tn)
+      for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int r = 0; r < 4; ++r) stage[(4 * q + r) * kLd + tn * 16 + i16] = acc[tm][tn][r];
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int lrow = it * 4 + q, row = row_base + lrow;
+      for (int it = 0; it < 16 / kRowsPerIt; ++it) {
+        const int lrow = it * kRowsPerIt + rsub, row = row_base + lrow;
         v4f val = *reinterpret_cast<const v4f*>(stage + lrow * kLd + c4) + bias;
         if (row < row_end && col_ok) {
           if (p.relu) {
@@ -709,8 +731,8 @@ __global__ __launch_bounds__(kThreads240, kWm240 * kWn240 / 4) void gemm_rows240
       __builtin_amdgcn_wave_barrier();
     } else {
 #pragma unroll
-      for (int tn = 0; tn < kTn240; ++tn) {
-        const int c = n0 + wn * (kC240 / kWn240) + tn * 16 + i16;
+      for (int tn = 0; tn < TN; ++tn) {
+        const int c = n0 + wn * WTN + tn * 16 + i16;
         const float bs = (p.bias != nullptr && c < p.rb) ? p.bias[c] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -729,10 +751,10 @@ __global__ __launch_bounds__(kThreads240, kWm240 * kWn240 / 4) void gemm_rows240
   Probe::mark(3);
 }
 
-template <class Probe = NoProbe>
-int launch_rows240_direct(const GemmArgs& p, hipStream_t st) {
+template <int WM, int WN, int DEPTH, class Probe = NoProbe>
+int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
   dim3 grid((p.ra + kR240 - 1) / kR240, (p.rb + kC240 - 1) / kC240, 1);
-  gemm_rows240_direct_kernel<Probe><<<grid, kThreads240, 0, st>>>(p);
+  gemm_panel_direct_kernel<WM, WN, DEPTH, Probe><<<grid, 64 * WM * WN, 0, st>>>(p);
   return launch_status();
 }
 
@@ -903,9 +925,12 @@ inline bool aligned4(int64_t x) { return (x & 3) == 0; }
 
 // Tile configurations (runtime-selectable for tuning through gts_set_option).
 // Defaults from tools/tune_gemm.py at M = 60 000, 256-wide (profiles/r01_tune_gemm.log).
-int g_fwd_variant = -1;    // forward kernels (both operands kk-contiguous); -1 = a one-round tile (9 = 240-row
-                           // panels on the 16x16x4 MFMA when they leave fewer rows per CU, else 8 = double-buffered
-                           // 256x256) when that fills >= 3/4 of the CUs, else 3 (64x256, two per CU)
+int g_fwd_variant = -1;    // forward kernels (both operands kk-contiguous); -1 = a one-round tile (10 = 240-row
+                           // panels on the 16x16x4 MFMA with direct-to-fragment loads when panels leave fewer rows
+                           // per CU, else 8 = double-buffered 256x256) when that fills >= 3/4 of the CUs, else 3
+                           // (64x256, two per CU).  profiles/r02_tune_gemm.log: at M = 60 000, 256-wide, K = 256 / 512:
+                           // 8: 74.7 / 137.5 us, 9 (same panels through LDS): 73.1 / 134.3, 10: 70.4 / 129.8,
+                           // 11 / 12 (one 240 x 64 wave per SIMD, depth 1 / 2): 74.2 / 129.7, 76.0 / 134.1
 int g_igrad_variant = 1;   // input-gradient kernels (B kk-strided)
 int g_wgrad_variant = -1;  // split-reduction kernel; -1 = chosen per launch by wgrad_plan()
 
@@ -932,12 +957,14 @@ int launch_plain(const GemmArgs& p, hipStream_t st) {
       // one workgroup per CU, in rounds of 256: rows a CU walks with 256-row tiles vs 240-row panels
       const int64_t panels = static_cast<int64_t>((p.ra + kR240 - 1) / kR240) * cols;
       const int64_t rows256 = (big_tiles + 255) / 256 * 256, rows240 = (panels + 255) / 256 * kR240;
-      if (variant == 8 && rows240 < rows256) variant = 9;
+      if (variant == 8 && rows240 < rows256) variant = 10;
     }
   }
   if constexpr (AKC && BKC) {
     if (variant == 9) return launch_rows240(p, st);
-    if (variant == 10) return launch_rows240_direct(p, st);
+    if (variant == 10) return launch_panel_direct<3, 4, 1>(p, st);
+    if (variant == 11) return launch_panel_direct<1, 4, 1>(p, st);
+    if (variant == 12) return launch_panel_direct<1, 4, 2>(p, st);
   }
   switch (variant) {
     // the variants that survived the sweeps in profiles/r01_tune_gemm.log (numbers kept from there)

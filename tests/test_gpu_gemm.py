@@ -72,29 +72,30 @@ def test_linear_forward_one_round_tile(m, k, n, dual):
 def test_forward_tile_variants_are_bitwise_identical_at_full_size(hip_lib, m, f, dual):
     """Every 32x32x2 tile variant walks the reduction in the same order, so the C2- / C3-sized forward
     GEMM of the one-round 256x256 tile equals the 64x256 / 128x256 tiles the small-graph parity tests
-    exercise, bit for bit.  The 240-row panels (variant 9, what -1 selects at these sizes) run on the
-    16x16x4 MFMA, which adds four products per step instead of two: equal to fp32 rounding (checked
+    exercise, bit for bit.  The 240-row panels (variants 9 and 10; 10 is what -1 selects at these sizes) run
+    on the 16x16x4 MFMA, which adds four products per step instead of two: equal to fp32 rounding (checked
     against fp64 in the tests below), deterministic, and what the automatic choice returns."""
     a0, w0, b = _rand(m, f, seed=21).to(DEV), _rand(f, f, seed=23).to(DEV), _rand(f, seed=25).to(DEV)
     a1, w1 = (_rand(m, f, seed=22).to(DEV), _rand(f, f, seed=24).to(DEV)) if dual else (None, None)
     outs = {}
     try:
-        for variant in (8, 3, 1, 9, -1, 9):
+        for variant in (8, 3, 1, 9, 10, -1, 10):
             assert hip_lib.gts_set_option(1, variant) == 0
             outs.setdefault(variant, []).append(dense.linear_fwd(a0, w0, a1, w1, bias=b, relu=True))
     finally:
         hip_lib.gts_set_option(1, -1)
     assert torch.equal(outs[8][0], outs[3][0]) and torch.equal(outs[8][0], outs[1][0])
-    assert torch.equal(outs[9][0], outs[9][1]) and torch.equal(outs[9][0], outs[-1][0])
+    assert torch.equal(outs[10][0], outs[10][1]) and torch.equal(outs[10][0], outs[-1][0])
+    assert torch.equal(outs[9][0], outs[10][0])      # both 16x16x4 kernels consume the reduction in the same order
     scale = float(outs[8][0].abs().max())
-    assert float((outs[9][0] - outs[8][0]).abs().max()) < 1e-5 * scale
+    assert float((outs[10][0] - outs[8][0]).abs().max()) < 1e-5 * scale
 
 
 ROWS240 = [(240, 256, 256, 0), (239, 64, 256, 64), (241, 32, 260, 0), (1000, 132, 132, 260), (60000, 256, 256, 256),
            (49999, 260, 1024, 0), (481, 4, 8, 4), (5, 36, 4, 0), (120000, 256, 256, 0)]
 
 
-@pytest.mark.parametrize("variant", [9, 10])
+@pytest.mark.parametrize("variant", [9, 10, 11, 12])
 @pytest.mark.parametrize("m,k0,n,k1", ROWS240)
 @pytest.mark.parametrize("relu,bias,mask", [(True, True, False), (False, False, True)])
 def test_rows240_panels_against_fp64(hip_lib, m, k0, n, k1, relu, bias, mask, variant):

@@ -49,7 +49,9 @@ extern "C" int gts_probe_linear_fwd(const float* a0, const float* w0, const floa
     case 3: return launch_tiles<64, 256, 2, 4, true, true, false, StampProbe>(p, 1, 1, st);
     case 8: return launch_tiles<256, 256, 4, 4, true, true, true, StampProbe>(p, 1, 1, st);
     case 9: return launch_rows240<StampProbe>(p, st);
-    case 10: return launch_rows240_direct<StampProbe>(p, st);
+    case 10: return launch_panel_direct<3, 4, 1, StampProbe>(p, st);
+    case 11: return launch_panel_direct<1, 4, 1, StampProbe>(p, st);
+    case 12: return launch_panel_direct<1, 4, 2, StampProbe>(p, st);
     default: return launch_tiles<128, 256, 2, 4, true, true, false, StampProbe>(p, 1, 1, st);
   }
 }

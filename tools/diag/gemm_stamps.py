@@ -27,7 +27,7 @@ x = torch.randn(M, F, device="cuda"); y = torch.randn(M, F, device="cuda")
 w = torch.randn(F, F, device="cuda") * 0.05; w2 = torch.randn(F, F, device="cuda") * 0.05
 b = torch.randn(F, device="cuda"); out = torch.empty(M, F, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
-for variant, bm, bn in ((8, 256, 256), (9, 240, 256), (10, 240, 256)):
+for variant, bm, bn in ((9, 240, 256), (11, 240, 256), (12, 240, 256)):
     n_blocks = ((M + bm - 1) // bm) * ((F + bn - 1) // bn)
     stamps = torch.zeros(8 * n_blocks, dtype=torch.int64, device="cuda")
     for dual in (False, True):
@@ -57,7 +57,7 @@ for variant, bm, bn in ((8, 256, 256), (9, 240, 256), (10, 240, 256)):
 
 # A operand cache-hot (row stride 0): is the main loop waiting on A from HBM?
 lib.gts_probe_set_buffer(None)
-for variant in (8, 9, 10):
+for variant in (9, 10, 11, 12):
     for hot in (0, 1):
         for dual in (False, True):
             args = (x.data_ptr(), w.data_ptr(), y.data_ptr() if dual else None, w2.data_ptr() if dual else None,
