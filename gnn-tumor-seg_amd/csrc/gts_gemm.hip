@@ -758,6 +758,127 @@ int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
   return launch_status();
 }
 
+// ---- weight gradients, operands straight into MFMA fragments ------------------------------------
+// C[n, k] = sum_m g[m, n] act[m, k] (one split of the node range per blockIdx.z, slabs as above).
+// Both operands have the reduction index m as their ROW index, so a lane cannot fetch four
+// consecutive reduction steps with one load.  It fetches four consecutive COLUMNS instead:
+// lane (c, q) loads g[m + q][nb + 4 c .. + 3] (16 lanes = 256 contiguous bytes of one row) and the
+// four components feed four MFMAs of four INTERLEAVED 16-row tiles (tile t = rows nb + 4 i + t),
+// each consuming the reduction steps m .. m + 3 (one per lane quarter).  The same on the act side;
+// accumulator (t, t') then holds C[nb + 4 (4 q + r) + t][kb + 4 c + t'], so the four t' registers
+// of a lane are one contiguous 16-byte piece of a C row: the tile leaves without any staging.
+// 16 waves of 64 x 64 outputs, no LDS, no barriers; DEPTH + 1 register pairs of fragments per wave
+// (the loads of the next DEPTH reduction steps are in flight under the 16 MFMAs of a step).
+template <int DEPTH, class Probe = NoProbe>
+__global__ __launch_bounds__(1024, 4) void wgrad_direct_kernel(const GemmArgs p) {
+  constexpr int R = DEPTH + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int c16 = lane & 15, q = lane >> 4;
+  const int problem = blockIdx.y / p.tiles_n, tile_n = blockIdx.y % p.tiles_n;
+  const int nb = blockIdx.x * 256 + wm * 64, kb = tile_n * 256 + wn * 64;
+  const float* g = kernarg_entry<const float*>(offsetof(GemmArgs, pa), problem);
+  const float* act = kernarg_entry<const float*>(offsetof(GemmArgs, pb), problem);
+  const int ldg = p.lda[0], lda = p.ldb[0];
+  const int m_beg = min(p.kseg[0], static_cast<int>(blockIdx.z) * p.tiles_per_split * kBK);
+  const int m_end = min(p.kseg[0], m_beg + p.tiles_per_split * kBK);
+  // rows [m_beg, m_end) of both operands
+  __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g + static_cast<size_t>(m_beg) * ldg), 0, (m_end - m_beg) * ldg * 4, 0x00020000);
+  __amdgpu_buffer_rsrc_t ract = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(act + static_cast<size_t>(m_beg) * lda), 0, (m_end - m_beg) * lda * 4, 0x00020000);
+  // lane offsets are loop-invariant (a lane whose four columns lie past the matrix is parked outside
+  // the resource and reads 0); the reduction step advances through the wave-uniform scalar offset
+  const bool g_ok = nb + 4 * c16 < p.ra, a_ok = kb + 4 * c16 < p.rb;
+  const unsigned vg = g_ok ? static_cast<unsigned>(q * ldg + nb + 4 * c16) * 4 : kOutOfRange;
+  const unsigned va = a_ok ? static_cast<unsigned>(q * lda + kb + 4 * c16) * 4 : kOutOfRange;
+
+  v4acc acc[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[t][u] = v4acc{0.f, 0.f, 0.f, 0.f};
+  v4f csum = {0.f, 0.f, 0.f, 0.f};
+  // the column sums of g (bias gradient) ride on ONE wave per row block and SIMD: (wm, wn = wm)
+  const bool want_colsum = p.colsum != nullptr && tile_n == 0 && wn == wm;
+
+  Probe::mark(0);
+  const int steps = (m_end - m_beg) / 4, ragged = (m_end - m_beg) % 4;   // 4 reduction rows per MFMA step
+  v4f gf[R], af[R];
+  auto fetch = [&](int slot, int step) {   // step is clamped by the callers: never past the last whole step
+    gf[slot] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rg, vg, step * ldg * 16, 0));
+    af[slot] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ract, va, step * lda * 16, 0));
+  };
+  auto multiply = [&](int slot, auto with_colsum) {
+    if constexpr (decltype(with_colsum)::value) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) csum[t] += gf[slot][t];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        acc[t][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[slot][t], af[slot][v], acc[t][v], 0, 0, 0);
+  };
+  auto reduce = [&](auto with_colsum) {
+    if (steps > 0) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) fetch(u, min(u, steps - 1));
+    }
+    int s = 0;
+    for (; s + R <= steps; s += R) {
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        fetch((u + DEPTH) % R, min(s + u + DEPTH, steps - 1));
+        multiply(u, with_colsum);
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u) {   // pin the pipeline: a step's two loads in front of the step's MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        if constexpr (decltype(with_colsum)::value) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < R - 1; ++u)   // the last steps % R steps: their fragments are already on the way
+      if (s + u < steps) multiply(u, with_colsum);
+    if (ragged != 0) {   // 1-3 rows left: the lane quarters past them read outside the resource
+      gf[0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rg, q < ragged ? vg : kOutOfRange, steps * ldg * 16, 0));
+      af[0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ract, q < ragged ? va : kOutOfRange, steps * lda * 16, 0));
+      multiply(0, with_colsum);
+    }
+  };
+  Probe::mark(1);
+  if (want_colsum) reduce(std::true_type{});
+  else reduce(std::false_type{});
+  Probe::mark(2);
+
+  const size_t slab = static_cast<size_t>(problem) * p.n_splits + blockIdx.z;
+  float* c = p.c + slab * p.ra * p.ldc;
+  const int col = kb + 4 * c16;
+  if (col < p.rb) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = nb + 4 * (4 * q + r) + t;
+        if (row < p.ra)
+          *reinterpret_cast<v4f*>(c + static_cast<size_t>(row) * p.ldc + col) =
+              v4f{acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+      }
+  }
+  if (want_colsum) {   // the four lane quarters hold the rows m = q (mod 4): add them in quarter order
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float q1 = __shfl(csum[t], c16 + 16, kWave), q2 = __shfl(csum[t], c16 + 32, kWave),
+                  q3 = __shfl(csum[t], c16 + 48, kWave);
+      csum[t] = ((csum[t] + q1) + q2) + q3;
+    }
+    if (q == 0 && g_ok) *reinterpret_cast<v4f*>(p.colsum + slab * p.ra + nb + 4 * c16) = csum;
+  }
+  Probe::mark(3);
+}
+
 // out_q[i] = sum_s slab[q][s][i] for problems q, summed in split order inside four interleaved
 // split groups whose partials are then added in group order: a fixed association, so results
 // are bitwise reproducible.  One float4 column per thread-quad.
@@ -985,7 +1106,7 @@ inline void wgrad_candidate(int variant, int64_t k, int* bm, int* bn, int64_t* s
   *bm = 128, *bn = k <= 64 ? 64 : 128, *slots = 512;   // 2 workgroups per CU
   if (k <= 64) return;
   if (variant == 2) *bn = 256;
-  if (variant == 4) *bm = 256, *bn = 256, *slots = 256;  // double-buffered: one workgroup per CU
+  if (variant == 4 || variant == 5) *bm = 256, *bn = 256, *slots = 256;  // one workgroup per CU
 }
 
 inline WgradPlan wgrad_plan(int64_t m, int64_t n, int64_t k, int n_problems) {
@@ -1023,6 +1144,13 @@ int launch_wgrad(const GemmArgs& p, const WgradPlan& plan, hipStream_t st) {
   switch (plan.variant) {
     case 2: return launch_tiles<128, 256, 2, 4, false, false>(p, np, splits, st);
     case 4: return launch_tiles<256, 256, 4, 4, false, false, true>(p, np, splits, st);
+    case 5: {
+      GemmArgs q = p;
+      q.tiles_n = (p.rb + 255) / 256;
+      dim3 grid((p.ra + 255) / 256, q.tiles_n * np, splits);
+      wgrad_direct_kernel<5><<<grid, 1024, 0, st>>>(q);
+      return launch_status();
+    }
     default: return launch_tiles<128, 128, 2, 4, false, false>(p, np, splits, st);   // 1
   }
 }

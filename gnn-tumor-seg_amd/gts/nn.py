@@ -327,12 +327,22 @@ class _GATLayer(torch.autograd.Function):
         g_al, g_ar = ops.gat_param_grad(ft, gel, ger)
         gft2 = gft.view(n, heads * dim)
         g_wres = None
+        # wide layers: the input gradient runs in the forward GEMM's form on transposed weights
+        turn = TRANSPOSED_IGRAD and need[1] and w_fc.shape[1] >= 128 and w_fc.shape[0] % 4 == 0 \
+            and w_fc.shape[1] % 4 == 0 and n >= 4096
         if w_res is not None:
             (g_wfc, _), (g_wres, _) = dense.linear_bwd_weight_multi([(gft2, h, False), (g_pre, h, False)])
-            gh = dense.linear_bwd_input(gft2, w_fc, g_pre, w_res) if need[1] else None
+            if turn:
+                wt = dense.transpose_batch([w_fc, w_res])
+                gh = dense.linear_bwd_input_t(gft2, wt[0], g_pre, wt[1])
+            else:
+                gh = dense.linear_bwd_input(gft2, w_fc, g_pre, w_res) if need[1] else None
         else:
             g_wfc, _ = dense.linear_bwd_weight(gft2, h)
-            gh = dense.linear_bwd_input(gft2, w_fc) if need[1] else None
+            if turn:
+                gh = dense.linear_bwd_input_t(gft2, dense.transpose_batch([w_fc])[0])
+            else:
+                gh = dense.linear_bwd_input(gft2, w_fc) if need[1] else None
             if gh is not None and ctx.identity_res:
                 gh = gh + g_pre
         return (None, gh, g_wfc, g_al.view(ctx.attn_shape), g_ar.view(ctx.attn_shape), g_bias, g_wres,
