@@ -1070,6 +1070,7 @@ int launch_plain(const GemmArgs& p, hipStream_t st) {
   if (p.rb <= 64) return launch_tiles<128, 64, 2, 2, AKC, BKC>(p, 1, 1, st);
   if (p.rb <= 128) return launch_tiles<128, 128, 2, 2, AKC, BKC>(p, 1, 1, st);
   int variant = BKC ? g_fwd_variant : g_igrad_variant;
+  const bool row_count_invariant = variant == -2;   // automatic, but only 32x32x2 tiles: one reduction order
   if (variant < 0) {
     const int64_t cols = (p.rb + 255) / 256;
     const int64_t big_tiles = static_cast<int64_t>((p.ra + 255) / 256) * cols;
@@ -1078,7 +1079,7 @@ int launch_plain(const GemmArgs& p, hipStream_t st) {
       // one workgroup per CU, in rounds of 256: rows a CU walks with 256-row tiles vs 240-row panels
       const int64_t panels = static_cast<int64_t>((p.ra + kR240 - 1) / kR240) * cols;
       const int64_t rows256 = (big_tiles + 255) / 256 * 256, rows240 = (panels + 255) / 256 * kR240;
-      if (variant == 8 && rows240 < rows256) variant = 10;
+      if (variant == 8 && rows240 < rows256 && !row_count_invariant) variant = 10;
     }
   }
   if constexpr (AKC && BKC) {

@@ -19,6 +19,27 @@ from ._lib import check, current_stream, ptr, require_device
 GEMM_TIMER = None
 
 
+class row_count_invariant:
+    """Context manager: forward GEMMs inside pick their tile among the 32x32x2 variants only, which all
+    walk the reduction in one order — a row's result is then independent of how many rows the call has
+    (the 240-row panels chosen for very tall operands run on the 16x16x4 MFMA and round differently).
+    Used where a batched forward must reproduce per-sample forwards bit for bit (GNN.evaluate)."""
+
+    _depth = 0
+
+    def __enter__(self):
+        if row_count_invariant._depth == 0:
+            check(_lib.load().gts_set_option(1, -2), "gts_set_option")
+        row_count_invariant._depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        row_count_invariant._depth -= 1
+        if row_count_invariant._depth == 0:
+            check(_lib.load().gts_set_option(1, -1), "gts_set_option")
+        return False
+
+
 def _timed(kind, flops, launch):
     return GEMM_TIMER(kind, flops, launch) if GEMM_TIMER is not None else launch()
 

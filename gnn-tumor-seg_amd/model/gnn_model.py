@@ -25,6 +25,7 @@ from torch.utils.data import DataLoader
 
 from data_processing.data_loader import ImageGraphDataset, minibatch_graphs
 from data_processing.graph_io import project_nodes_to_img
+from gts import dense as gdense
 from gts import dist as gdist
 from gts import ops as gops
 from gts.optim import FlatAdamW
@@ -33,6 +34,7 @@ from . import evaluation
 from .networks import init_graph_net
 
 BATCH_SIZE = 6
+EVAL_BATCH_SIZE = 8     # samples per batched evaluation forward (the reference evaluates one at a time)
 
 
 class _ShardedBatches:
@@ -219,7 +221,7 @@ class GNN:
         self.lr_decay.step()
         return np.mean(torch.stack(step_losses).cpu().double().numpy())
 
-    def evaluate(self, dataset: ImageGraphDataset):
+    def evaluate(self, dataset: ImageGraphDataset, batch_size=EVAL_BATCH_SIZE):
         """`dataset` is a torch Subset of an ImageGraphDataset with labels (what
         scripts/train_gnn.py passes).  Per sample: no-grad forward, weighted CE, arg-max; node
         metrics, then voxel metrics after projecting the predictions onto the supervoxel
@@ -227,32 +229,43 @@ class GNN:
         [n,8] label-count rows); metric columns: loss | node Dice WT,CT,ET | voxel Dice WT,CT,ET |
         voxel HD95 WT,CT,ET.
 
-        Everything up to the Dice quotients stays on the GPU: arg-max + projection is one K12
-        pass, the node- and voxel-level label coincidences are counted by K15, and only the two
-        5x5 integer tables, the loss and the predicted volume (for the scipy distance transforms
-        of HD95) travel to the host.  The integers are the ones the reference counts with numpy
-        masks, so every metric is the same double."""
+        The forwards are BATCHED (`batch_size` samples per block-diagonal union, one launch chain
+        instead of one per sample); rows of a block-diagonal batch never mix, and the GEMMs are pinned
+        to the tile family whose rounding does not depend on the row count, so every logit — hence
+        every loss, count and Dice — is the double the one-sample-at-a-time route of the reference
+        produces (tests/test_gpu_cli.py).  Everything up to the Dice quotients stays on the GPU:
+        arg-max + projection is one K12 pass per sample, the node- and voxel-level label
+        coincidences are counted by K15, and only the two 5x5 integer tables, the loss and the
+        predicted volume (for the scipy distance transforms of HD95) travel to the host."""
         assert dataset.dataset.read_label == True  # noqa: E712
         self.net.eval()
         source = dataset.dataset        # Subset -> underlying ImageGraphDataset
         metric_rows, count_rows = [], []
-        for mri_id, graph, feats, labels in dataset:
+        n_samples = len(dataset)
+        for first in range(0, n_samples, max(1, int(batch_size))):
+            samples = [dataset[i] for i in range(first, min(n_samples, first + max(1, int(batch_size))))]
+            ids, graph, feats, labels = minibatch_graphs(samples)
             graph, feats, labels = self._to_device(graph, feats, labels)
-            partitioning = torch.from_numpy(source.get_supervoxel_partitioning(mri_id)).to(self.device)
-            true_voxels = source.get_voxel_labels(mri_id)
-            with torch.no_grad():
-                logits = self.net(graph, feats)
-                loss = self.loss_fcn(logits, labels)
-                predicted = torch.max(logits, dim=1)[1]
-                node_table = gops.label_confusion(predicted.to(torch.int16), labels.to(torch.int16))
-                predicted_voxels = gops.project_argmax(partitioning, logits)          # K12 + arg-max
-                voxel_table = gops.label_confusion(                                  # K15
-                    predicted_voxels, torch.from_numpy(true_voxels).to(self.device).contiguous())
-            tables = torch.stack([node_table, voxel_table]).cpu().numpy()
-            hd95s = evaluation.calculate_hd95s(predicted_voxels.cpu().numpy(), true_voxels)
-            metric_rows.append(np.concatenate([[loss.item()], evaluation.dices_from_confusion(tables[0]),
-                                               evaluation.dices_from_confusion(tables[1]), hd95s]))
-            count_rows.append(evaluation.label_counts_from_confusion(tables[0]))
+            with torch.no_grad(), gdense.row_count_invariant():
+                all_logits = self.net(graph, feats)
+            ends = np.cumsum([s[1].number_of_nodes() for s in samples])
+            for j, mri_id in enumerate(ids):
+                lo, hi = int(ends[j - 1]) if j else 0, int(ends[j])
+                logits, node_labels = all_logits[lo:hi], labels[lo:hi]
+                partitioning = torch.from_numpy(source.get_supervoxel_partitioning(mri_id)).to(self.device)
+                true_voxels = source.get_voxel_labels(mri_id)
+                with torch.no_grad():
+                    loss = self.loss_fcn(logits, node_labels)
+                    predicted = torch.max(logits, dim=1)[1]
+                    node_table = gops.label_confusion(predicted.to(torch.int16), node_labels.to(torch.int16))
+                    predicted_voxels = gops.project_argmax(partitioning, logits)          # K12 + arg-max
+                    voxel_table = gops.label_confusion(                                  # K15
+                        predicted_voxels, torch.from_numpy(true_voxels).to(self.device).contiguous())
+                tables = torch.stack([node_table, voxel_table]).cpu().numpy()
+                hd95s = evaluation.calculate_hd95s(predicted_voxels.cpu().numpy(), true_voxels)
+                metric_rows.append(np.concatenate([[loss.item()], evaluation.dices_from_confusion(tables[0]),
+                                                   evaluation.dices_from_confusion(tables[1]), hd95s]))
+                count_rows.append(evaluation.label_counts_from_confusion(tables[0]))
         metrics = np.array(metric_rows).reshape(len(metric_rows), 10)
         counts = np.array(count_rows).reshape(len(count_rows), 8)
         return np.mean(metrics, axis=0), np.sum(counts, axis=0)

@@ -87,7 +87,10 @@ def test_evaluate_on_device_counts_equal_the_host_route(tmp_path):
     for _ in range(3):
         model.run_epoch()
     subset = torch.utils.data.Subset(ds, [0, 1, 2, 3])
-    metrics, counts = model.evaluate(subset)
+    metrics, counts = model.evaluate(subset)                     # one batched forward of the four samples
+    for batch_size in (1, 3):                                    # one at a time / a ragged last batch: same doubles
+        again = model.evaluate(subset, batch_size=batch_size)
+        assert np.array_equal(again[0], metrics) and np.array_equal(again[1], counts)
     rows, count_rows = [], []
     for mri_id, graph, feats, labels in subset:
         with torch.no_grad():

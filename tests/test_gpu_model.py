@@ -544,3 +544,25 @@ def test_prefetched_epochs_equal_plain_epochs_and_errors_surface():
     next(batches)
     batches.close()
     assert np.isfinite(model.run_epoch())
+
+
+def test_row_count_invariant_batched_forward_is_bitwise_the_per_sample_forward():
+    """What GNN.evaluate relies on: under dense.row_count_invariant() a block-diagonal batch tall enough
+    to select the 240-row panels otherwise (8 x 7 000 nodes) gives every sample the logits of its own
+    one-sample forward, bit for bit; without the pin the batch rounds differently (16x16x4 MFMA)."""
+    from gts import dense
+
+    parts = [synth.random_graph(n=7000, n_pairs=14000, seed=50 + i) for i in range(8)]
+    feats = [torch.from_numpy(synth.node_features(7000, 20, 50 + i)) for i in range(8)]
+    _, mine = _net_pair("GSpool", HP(20, 4, [256] * 4, None, None), seed=4)
+    mine.eval()
+    with torch.no_grad():
+        sep = torch.cat([mine(p.to(DEV), f.to(DEV)) for p, f in zip(parts, feats)])
+        g, x = gts.batch(parts).to(DEV), torch.cat(feats).to(DEV)
+        with dense.row_count_invariant():
+            pinned = mine(g, x)
+        free = mine(g, x)
+    assert torch.equal(pinned, sep)
+    assert not torch.equal(free, sep) and torch.allclose(free, sep, rtol=1e-4, atol=1e-4)
+    with torch.no_grad():                          # the pin is released on exit
+        assert torch.equal(mine(g, x), free)
