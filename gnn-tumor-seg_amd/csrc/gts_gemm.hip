@@ -35,7 +35,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kBK = 32;         // reduction elements per LDS tile
 constexpr int kKcLd = kBK + 4;  // padded row of a kk-contiguous LDS image
 constexpr int kMaxProblems = 32;
-int g_gemm_sched = 0;           // GemmArgs::sched (GTS_OPT_GEMM_SCHED)
+int g_gemm_sched = 1;           // GemmArgs::sched (GTS_OPT_GEMM_SCHED); bit 0 on: -0.9 % on the 19-problem weight-gradient launch
 
 struct GemmArgs {
   const float* a[2];    // forward / input grad: the two (a, b) reduction segments
@@ -725,7 +725,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
 #pragma unroll
             for (int e = 0; e < 4; ++e) val[e] = mk[it][e] > 0.f ? val[e] : 0.f;
           }
-          *reinterpret_cast<v4f*>(p.c + static_cast<size_t>(row) * p.ldc + col) = val;
+          v4f* dst = reinterpret_cast<v4f*>(p.c + static_cast<size_t>(row) * p.ldc + col);
+          if (p.sched & 2) __builtin_nontemporal_store(val, dst);
+          else *dst = val;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -754,7 +756,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
 template <int WM, int WN, int DEPTH, class Probe = NoProbe>
 int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
   dim3 grid((p.ra + kR240 - 1) / kR240, (p.rb + kC240 - 1) / kC240, 1);
-  gemm_panel_direct_kernel<WM, WN, DEPTH, Probe><<<grid, 64 * WM * WN, 0, st>>>(p);
+  GemmArgs q = p;
+  q.sched = g_gemm_sched;
+  gemm_panel_direct_kernel<WM, WN, DEPTH, Probe><<<grid, 64 * WM * WN, 0, st>>>(q);
   return launch_status();
 }
 

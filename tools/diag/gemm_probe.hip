@@ -21,6 +21,18 @@ struct StampProbe {
   }
 };
 
+// per-WAVE stamps (lane 0 of every wave; no barrier): for the kernels whose waves run independently
+struct WaveProbe {
+  __device__ __forceinline__ static void mark(int phase) {
+    if ((threadIdx.x & 63) == 0 && g_probe != nullptr) {
+      const size_t wg = static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x;
+      const size_t at = (((wg * (blockDim.x >> 6)) + (threadIdx.x >> 6)) * 4 + phase) * 2;
+      g_probe[at] = __builtin_amdgcn_s_memrealtime();
+      g_probe[at + 1] = __builtin_amdgcn_s_memtime();
+    }
+  }
+};
+
 }  // namespace
 }  // namespace gts
 
@@ -50,6 +62,7 @@ extern "C" int gts_probe_linear_fwd(const float* a0, const float* w0, const floa
     case 8: return launch_tiles<256, 256, 4, 4, true, true, true, StampProbe>(p, 1, 1, st);
     case 9: return launch_rows240<StampProbe>(p, st);
     case 10: return launch_panel_direct<3, 4, 1, StampProbe>(p, st);
+    case 110: return launch_panel_direct<3, 4, 1, WaveProbe>(p, st);
     case 11: return launch_panel_direct<1, 4, 1, StampProbe>(p, st);
     case 12: return launch_panel_direct<1, 4, 2, StampProbe>(p, st);
     default: return launch_tiles<128, 256, 2, 4, true, true, false, StampProbe>(p, 1, 1, st);
