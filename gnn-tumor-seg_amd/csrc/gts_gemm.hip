@@ -883,6 +883,153 @@ __global__ __launch_bounds__(1024, 4) void wgrad_direct_kernel(const GemmArgs p)
   Probe::mark(3);
 }
 
+// ---- weight gradients, operand tiles by LDS-DMA ------------------------------------------------
+// Same 256 x 256 tile, split-reduction slabs and 32x32x2 MFMA reduction order as the
+// double-buffered gemm_kernel<256, 256, 4, 4, false, false, true>, with two changes:
+//   * the [32 rows][256 floats] LDS image of a reduction-strided operand is a byte-for-byte copy
+//     of 32 global row pieces of 1 KiB, so the tiles travel global -> LDS by `buffer_load ... lds`
+//     (one 1 KiB piece per wave instruction, four pieces per wave and tile): no staging registers,
+//     no ds_write, and rows / columns past the operand read as zeros through the buffer resource;
+//   * the single-word fragment reads of MFMA step s are written three steps ahead of their use.
+// Measured (tools/diag/wgrad_stamps.py, profiles/r02_wgrad_stamps.log): exactly the cycles of the
+// register-staged tile — 2.704 M shader cycles per workgroup = 87.9 % of the matrix pipe — and 95.2 %
+// with the LDS fragment reads removed: what bounds both is the ISSUE of the 32 ds_read2_b32 per wave
+// and tile beside the MFMAs (~11 cycles of lost MFMA issue each), not latency and not the tile copy.
+// One barrier per tile, in front of step 13: by then a wave has issued (and waits for) every read of
+// this tile's image and its own DMA pieces of the next tile; after it the next image is complete,
+// this one is free, the DMA of tile t+2 goes into it and steps 13-15 prefetch from the next image.
+template <class Probe = NoProbe, int EXPERIMENT = 0>   // EXPERIMENT != 0: timing experiments of tools/diag only (wrong results)
+__global__ __launch_bounds__(1024, 4) void wgrad_dma_kernel(const GemmArgs p) {
+  constexpr int BM = 256, BN = 256, WM = 4, WN = 4, WTM = 64, WTN = 64, TM = 2, TN = 2;
+  constexpr int kImage = kBK * (BM + BN);   // floats: A image then B image
+  __shared__ float lds[2 * kImage];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int i = lane & 31, h = lane >> 5;
+  const int problem = blockIdx.y / p.tiles_n, tile_n = blockIdx.y % p.tiles_n;
+  const int m0 = blockIdx.x * BM, n0 = tile_n * BN;   // output rows (columns of g) / output columns (columns of act)
+  const float* g = kernarg_entry<const float*>(offsetof(GemmArgs, pa), problem);
+  const float* act = kernarg_entry<const float*>(offsetof(GemmArgs, pb), problem);
+  const int ldg = p.lda[0], lda = p.ldb[0];
+  const int n_tiles_all = (p.kseg[0] + kBK - 1) / kBK;
+  const int t_beg = min(n_tiles_all, static_cast<int>(blockIdx.z) * p.tiles_per_split);
+  const int t_end = min(n_tiles_all, t_beg + p.tiles_per_split);
+  const int row_beg = t_beg * kBK, rows = min(p.kseg[0], t_end * kBK) - row_beg;   // reduction rows of this split
+  __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g + static_cast<size_t>(row_beg) * ldg), 0, rows * ldg * 4, 0x00020000);
+  __amdgpu_buffer_rsrc_t ract = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(act + static_cast<size_t>(row_beg) * lda), 0, rows * lda * 4, 0x00020000);
+  // wave w copies rows w and w + 16 of both tiles; a lane whose four columns lie past the operand
+  // is parked outside the resource (zeros land in LDS)
+  const bool g_ok = m0 + 4 * lane < p.ra, a_ok = n0 + 4 * lane < p.rb;
+  const unsigned vg = g_ok ? static_cast<unsigned>(wave * ldg + m0 + 4 * lane) * 4 : kOutOfRange;
+  const unsigned va = a_ok ? static_cast<unsigned>(wave * lda + n0 + 4 * lane) * 4 : kOutOfRange;
+  const unsigned tile_g = g_ok ? static_cast<unsigned>(ldg) * kBK * 4 : 0, tile_a = a_ok ? static_cast<unsigned>(lda) * kBK * 4 : 0;
+  const unsigned half_g = g_ok ? static_cast<unsigned>(ldg) * 16 * 4 : 0, half_a = a_ok ? static_cast<unsigned>(lda) * 16 * 4 : 0;
+  auto dma = [&](int t, int image) {   // tile t (counted from t_beg) -> image; row offset in the checked voffset
+    float* ia = lds + image * kImage + wave * BM;
+    float* ib = lds + image * kImage + kBK * BM + wave * BN;
+    const unsigned og = vg + static_cast<unsigned>(t) * tile_g, oa = va + static_cast<unsigned>(t) * tile_a;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, ia, 16, og, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, ia + 16 * BM, 16, og + half_g, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ract, ib, 16, oa, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ract, ib + 16 * BN, 16, oa + half_a, 0, 0, 0);
+  };
+
+  v16f acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+  float csum[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) csum[tm] = 0.f;
+  const bool want_colsum = p.colsum != nullptr && tile_n == 0 && wn == 0;
+
+  float fa[4][TM], fb[4][TN];
+  auto frag_read = [&](int slot, const float* image, int step) {
+    const int kk = (step >> 2) * 8 + 4 * h + (step & 3);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) fa[slot][tm] = image[kk * BM + wm * WTM + tm * 32 + i];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) fb[slot][tn] = image[kBK * BM + kk * BN + wn * WTN + tn * 32 + i];
+  };
+
+  Probe::mark(0);
+  const int n_tiles = t_end - t_beg;
+  if (n_tiles > 0) {
+    dma(0, 0);
+    if (n_tiles > 1) {
+      dma(1, 1);
+      __builtin_amdgcn_s_waitcnt(0x0F70 | 4);   // vmcnt(4): the four pieces of tile 0 have landed
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 3; ++s) frag_read(s, lds, s);
+  }
+  Probe::mark(1);
+  auto mfma_step = [&](int slot) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) csum[tm] += want_colsum ? fa[slot][tm] : 0.0f;   // + 0 is exact
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][tm], fb[slot][tn], acc[tm][tn], 0, 0, 0);
+  };
+  for (int t = 0; t < n_tiles; ++t) {
+    const int cur = t & 1;
+    const float* img = lds + cur * kImage;
+    // past the last tile the three look-ahead steps re-read this image (never consumed)
+    const float* img_next = t + 1 < n_tiles ? lds + (cur ^ 1) * kImage : img;
+    // steps 0 .. 12: straight-line code, one scheduling region — per step the two LDS reads of step
+    // s + 3 (a ds_read2_b32 per operand), then the step's MFMAs
+#pragma unroll
+    for (int s = 0; s < 13; ++s) {
+      if (EXPERIMENT != 1) frag_read((s + 3) & 3, img, s + 3);
+      mfma_step(s & 3);
+    }
+#pragma unroll
+    for (int s = 0; s < 13; ++s) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, TM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+    }
+    if (EXPERIMENT != 2) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of tile t+1 are in LDS
+      __syncthreads();                       // (+ lgkmcnt(0)) image cur fully read, image cur^1 complete
+      if (t + 2 < n_tiles) dma(t + 2, cur);
+    }
+#pragma unroll
+    for (int s = 13; s < 16; ++s) {
+      if (EXPERIMENT != 1) frag_read((s + 3) & 3, img_next, s + 3 - 16);
+      mfma_step(s & 3);
+    }
+#pragma unroll
+    for (int s = 13; s < 16; ++s) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, TM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+    }
+  }
+  Probe::mark(2);
+  const size_t slab = static_cast<size_t>(problem) * p.n_splits + blockIdx.z;
+  write_tile<BM, BN, WM, WN>(p, lds, p.c + slab * p.ra * p.ldc, acc, m0, n0);
+  Probe::mark(3);
+  if (want_colsum) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const float total = csum[tm] + __shfl_xor(csum[tm], 32, kWave);  // the two kk halves
+      const int row = m0 + wm * WTM + tm * 32 + (lane & 31);
+      if ((lane >> 5) == 0 && row < p.ra) p.colsum[slab * p.ra + row] = total;
+    }
+  }
+}
+
 // out_q[i] = sum_s slab[q][s][i] for problems q, summed in split order inside four interleaved
 // split groups whose partials are then added in group order: a fixed association, so results
 // are bitwise reproducible.  One float4 column per thread-quad.
@@ -1111,7 +1258,7 @@ inline void wgrad_candidate(int variant, int64_t k, int* bm, int* bn, int64_t* s
   *bm = 128, *bn = k <= 64 ? 64 : 128, *slots = 512;   // 2 workgroups per CU
   if (k <= 64) return;
   if (variant == 2) *bn = 256;
-  if (variant == 4 || variant == 5) *bm = 256, *bn = 256, *slots = 256;  // one workgroup per CU
+  if (variant == 4 || variant == 5 || variant == 7) *bm = 256, *bn = 256, *slots = 256;  // one workgroup per CU
 }
 
 inline WgradPlan wgrad_plan(int64_t m, int64_t n, int64_t k, int n_problems) {
@@ -1149,6 +1296,13 @@ int launch_wgrad(const GemmArgs& p, const WgradPlan& plan, hipStream_t st) {
   switch (plan.variant) {
     case 2: return launch_tiles<128, 256, 2, 4, false, false>(p, np, splits, st);
     case 4: return launch_tiles<256, 256, 4, 4, false, false, true>(p, np, splits, st);
+    case 7: {
+      GemmArgs q = p;
+      q.tiles_n = (p.rb + 255) / 256;
+      dim3 grid((p.ra + 255) / 256, q.tiles_n * np, splits);
+      wgrad_dma_kernel<><<<grid, 1024, 0, st>>>(q);
+      return launch_status();
+    }
     case 5: {
       GemmArgs q = p;
       q.tiles_n = (p.rb + 255) / 256;

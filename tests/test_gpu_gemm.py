@@ -258,14 +258,16 @@ def test_input_gradient_from_transposed_weights(m, k, n0, n1, mask):
 
 @pytest.mark.parametrize("m,k,n,count", [(60000, 256, 256, 19), (3000, 256, 256, 3), (777, 132, 128, 5), (2049, 64, 128, 2),
                                          (515, 260, 256, 1), (37, 16, 12, 1), (4641, 256, 260, 4), (6, 32, 32, 1)])
-def test_direct_fragment_weight_gradient_against_fp64(hip_lib, m, k, n, count):
-    """wgrad_direct_kernel (GTS_OPT_WGRAD_TILE = 5: interleaved 16-row tiles fed by 16-byte column loads, no
-    LDS) forced on ragged node counts / widths / split boundaries, several problems per launch, bias sums."""
+@pytest.mark.parametrize("variant", [5, 7])
+def test_direct_fragment_weight_gradient_against_fp64(hip_lib, m, k, n, count, variant):
+    """The alternative 256 x 256 weight-gradient kernels (GTS_OPT_WGRAD_TILE = 5: interleaved 16-row tiles fed by
+    16-byte column loads, no LDS; 7: operand tiles moved by LDS-DMA, `buffer_load ... lds`) forced
+    on ragged node counts / widths / split boundaries, several problems per launch, bias sums."""
     gs = [_rand(m, n, seed=500 + q) for q in range(count)]
     acts = [_rand(m, k, seed=600 + q) for q in range(count)]
     dev = [(g.to(DEV), a.to(DEV), q % 2 == 0) for q, (g, a) in enumerate(zip(gs, acts))]
     try:
-        assert hip_lib.gts_set_option(2, 5) == 0
+        assert hip_lib.gts_set_option(2, variant) == 0
         out = dense.linear_bwd_weight_multi(dev)
         again = dense.linear_bwd_weight_multi(dev)
     finally:

@@ -14,7 +14,8 @@ struct StampProbe {
   __device__ __forceinline__ static void mark(int phase) {
     if (phase == 3) __syncthreads();
     if (threadIdx.x == 0 && g_probe != nullptr) {
-      const size_t at = ((static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4 + phase) * 2;
+      const size_t wg = (static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      const size_t at = (wg * 4 + phase) * 2;
       g_probe[at] = __builtin_amdgcn_s_memrealtime();
       g_probe[at + 1] = __builtin_amdgcn_s_memtime();
     }
@@ -67,4 +68,32 @@ extern "C" int gts_probe_linear_fwd(const float* a0, const float* w0, const floa
     case 12: return launch_panel_direct<1, 4, 2, StampProbe>(p, st);
     default: return launch_tiles<128, 256, 2, 4, true, true, false, StampProbe>(p, 1, 1, st);
   }
+}
+
+// the 19-problem weight-gradient launch (variant 4 = double-buffered LDS tile, 7 = LDS-DMA tiles) with stamps
+extern "C" int gts_probe_wgrad(const float* const* g, const float* const* a, int32_t n_problems, float* workspace,
+                               int64_t m, int64_t n, int64_t k, int32_t variant, int32_t splits, void* stream) {
+  using namespace gts;
+  GemmArgs p{};
+  for (int q = 0; q < n_problems; ++q) p.pa[q] = g[q], p.pb[q] = a[q];
+  p.a[0] = p.a[1] = g[0], p.b[0] = p.b[1] = a[0];
+  p.lda[0] = p.lda[1] = static_cast<int>(n), p.ldb[0] = p.ldb[1] = static_cast<int>(k);
+  p.kseg[0] = static_cast<int>(m), p.kseg[1] = 0;
+  p.ra = static_cast<int>(n), p.rb = static_cast<int>(k);
+  p.c = workspace, p.ldc = static_cast<int>(k);
+  p.colsum = nullptr;
+  p.n_problems = n_problems, p.n_splits = splits;
+  const int tiles = static_cast<int>((m + kBK - 1) / kBK);
+  p.tiles_per_split = (tiles + splits - 1) / splits;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (variant == 7 || variant == 71 || variant == 72) {
+    GemmArgs q = p;
+    q.tiles_n = (p.rb + 255) / 256;
+    dim3 grid((p.ra + 255) / 256, q.tiles_n * n_problems, splits);
+    if (variant == 7) wgrad_dma_kernel<StampProbe><<<grid, 1024, 0, st>>>(q);
+    if (variant == 71) wgrad_dma_kernel<StampProbe, 1><<<grid, 1024, 0, st>>>(q);   // no LDS fragment reads
+    if (variant == 72) wgrad_dma_kernel<StampProbe, 2><<<grid, 1024, 0, st>>>(q);   // no barrier, no DMA after the first two tiles
+    return launch_status();
+  }
+  return launch_tiles<256, 256, 4, 4, false, false, true, StampProbe>(p, n_problems, splits, st);
 }
