@@ -1269,13 +1269,19 @@ inline WgradPlan wgrad_plan(int64_t m, int64_t n, int64_t k, int n_problems) {
   // double-buffered 256x256 tile (4) and the 128x256 tile (2), the one whose workgroup count
   // (output tiles x splits, never more than the slots: no lone tail round) fills the chip best;
   // 19 problems: variant 4, 13 splits, 247 of 256 slots, 144 reduction tiles per workgroup.
+  // Few problems with LARGE outputs (GAT: one or two 1024 x 1024 gradients per layer, 16 output
+  // tiles of 256 x 256 x 16 splits = 256 workgroups): the double-buffered 256x256 tile again
+  // (C3 308 -> 312 graphs/s, profiles/r02_ab_c3_wgrad.log).
   static const int kMany[2] = {4, 2};
-  const int n_candidates = g_wgrad_variant >= 0 || n_problems <= 4 ? 1 : 2;
+  static const int kFewLarge[2] = {4, 1};
+  const bool few = n_problems <= 4;
+  const bool large = n * k * n_problems >= (1 << 20);
+  const int n_candidates = g_wgrad_variant >= 0 || (few && !large) ? 1 : 2;
   WgradPlan best{};
   double best_fill = -1.0;
   for (int c = 0; c < n_candidates; ++c) {
     WgradPlan plan{};
-    plan.variant = g_wgrad_variant >= 0 ? g_wgrad_variant : (n_problems <= 4 ? 1 : kMany[c]);
+    plan.variant = g_wgrad_variant >= 0 ? g_wgrad_variant : (few ? (large ? kFewLarge[c] : 1) : kMany[c]);
     int64_t slots;
     wgrad_candidate(plan.variant, k, &plan.bm, &plan.bn, &slots);
     const int64_t out_tiles = ((n + plan.bm - 1) / plan.bm) * ((k + plan.bn - 1) / plan.bn) * n_problems;
