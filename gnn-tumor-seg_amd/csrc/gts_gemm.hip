@@ -57,6 +57,12 @@ struct GemmArgs {
   int n_splits;
   int tiles_per_split;  // reduction tiles handled by one blockIdx.z
   int sched;            // tuning bits (GTS_OPT_GEMM_SCHED): 1 = waves further into a tile yield MFMA issue
+  // chained second GEMM of the panel kernels (c2 != null): c2[ra, rb2] = act2(c[ra, rb] . b2[rb2, rb]^T + bias2),
+  // computed by the workgroup that has just produced those rows of c (rb <= 256: one workgroup per row panel)
+  const float* b2;
+  const float* bias2;
+  float* c2;
+  int rb2, ldb2, ldc2, relu2;
 };
 
 // Phase probe of the kernel (start / operands staged / main loop done / tile stored).  The
@@ -600,19 +606,24 @@ __device__ __forceinline__ void mfma_group(v4acc (&acc)[TM][TN], const v4f (&af)
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tm][j], bf[tn][j], acc[tm][tn], 0, 0, 0);
 }
 
-template <int WM, int WN, int DEPTH, class Probe = NoProbe>
-__global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_kernel(const GemmArgs p) {
+struct PanelStage {   // one GEMM of the panel kernel: c[rows of the panel, rb] = act(a0 b0^T + a1 b1^T + bias) (. mask)
+  const float* a[2];
+  const float* b[2];
+  int lda[2], ldb[2], kseg[2];
+  int rb, ldc, relu;
+  float* c;
+  const float* bias;
+  const float* mask;
+};
+
+template <int WM, int WN, int DEPTH>
+__device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int sched, int m0, int n0, int row_end) {
   constexpr int WTM = kR240 / WM, WTN = kC240 / WN, TM = WTM / 16, TN = WTN / 16;
-  static_assert(WTM % 16 == 0 && WTN % 16 == 0 && WTN % 4 == 0 && (WM * WN) % 4 == 0, "wave tiles are whole 16x16 tiles");
   constexpr int R = DEPTH + 1;                     // register sets of fragments
   constexpr int kLd = WTN + 4, kStage = 16 * kLd;  // per-wave epilogue patch [16][WTN + 4]
-  __shared__ float lds[WM * WN * kStage];
-
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int i16 = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.x * kR240, n0 = blockIdx.y * kC240;
-  const int row_end = min(p.ra, m0 + kR240);
 
   v4acc acc[TM][TN];
 #pragma unroll
@@ -620,20 +631,18 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = v4acc{0.f, 0.f, 0.f, 0.f};
 
-  Probe::mark(0);
-  Probe::mark(1);
 #pragma unroll
   for (int seg = 0; seg < 2; ++seg) {
-    const int kseg = p.kseg[seg];
+    const int kseg = s.kseg[seg];
     if (kseg == 0) continue;
-    const int lda = p.lda[seg], ldb = p.ldb[seg];
+    const int lda = s.lda[seg], ldb = s.ldb[seg];
     // buffer resources over this workgroup's operand panels: rows [m0, row_end) of A, weight rows
     // [n0, n0 + 256) — anything past their last byte reads as 0 (no row clamps, no branches)
-    const int cols = min(p.rb - n0, kC240);
+    const int cols = min(s.rb - n0, kC240);
     __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.a[seg] + static_cast<size_t>(m0) * lda), 0, (row_end - m0) * lda * 4, 0x00020000);
+        const_cast<float*>(s.a[seg] + static_cast<size_t>(m0) * lda), 0, (row_end - m0) * lda * 4, 0x00020000);
     __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.b[seg] + static_cast<size_t>(n0) * ldb), 0, cols * ldb * 4, 0x00020000);
+        const_cast<float*>(s.b[seg] + static_cast<size_t>(n0) * ldb), 0, cols * ldb * 4, 0x00020000);
     unsigned off_a[TM], off_b[TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) off_a[tm] = (static_cast<unsigned>(wm * WTM + tm * 16 + i16) * lda + 4 * q) * 4;
@@ -680,30 +689,29 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
       mfma_group(acc, af[0], bf[0]);
     }
   }
-  Probe::mark(2);
 
   // Epilogue as in gemm_rows240_kernel: a row of TN tiles (16 x WTN outputs) through the wave's LDS
   // patch, out as 16-byte row segments with bias / ReLU / mask applied as float4.
   float* stage = lds + wave * kStage;
-  const bool wide = (p.rb & 3) == 0 && (p.ldc & 3) == 0;
+  const bool wide = (s.rb & 3) == 0 && (s.ldc & 3) == 0;
   constexpr int kC4 = WTN / 4;                // float4 per patch row
   constexpr int kRowsPerIt = 64 / kC4;        // patch rows one pass of the wave covers
   const int c4 = (lane % kC4) * 4, rsub = lane / kC4;
   const int col = n0 + wn * WTN + c4;
-  const bool col_ok = col < p.rb;
+  const bool col_ok = col < s.rb;
   v4f bias = {0.f, 0.f, 0.f, 0.f};
-  if (wide && p.bias != nullptr && col_ok) bias = *reinterpret_cast<const v4f*>(p.bias + col);
+  if (wide && s.bias != nullptr && col_ok) bias = *reinterpret_cast<const v4f*>(s.bias + col);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int row_base = m0 + wm * WTM + tm * 16;
     if (wide) {
       v4f mk[16 / kRowsPerIt];
-      if (p.mask != nullptr) {
+      if (s.mask != nullptr) {
 #pragma unroll
         for (int it = 0; it < 16 / kRowsPerIt; ++it) {
           const int row = row_base + it * kRowsPerIt + rsub;
           mk[it] = (row < row_end && col_ok)
-                       ? *reinterpret_cast<const v4f*>(p.mask + static_cast<size_t>(row) * p.ldc + col)
+                       ? *reinterpret_cast<const v4f*>(s.mask + static_cast<size_t>(row) * s.ldc + col)
                        : v4f{0.f, 0.f, 0.f, 0.f};
         }
       }
@@ -717,16 +725,16 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
         const int lrow = it * kRowsPerIt + rsub, row = row_base + lrow;
         v4f val = *reinterpret_cast<const v4f*>(stage + lrow * kLd + c4) + bias;
         if (row < row_end && col_ok) {
-          if (p.relu) {
+          if (s.relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
           }
-          if (p.mask != nullptr) {
+          if (s.mask != nullptr) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) val[e] = mk[it][e] > 0.f ? val[e] : 0.f;
           }
-          v4f* dst = reinterpret_cast<v4f*>(p.c + static_cast<size_t>(row) * p.ldc + col);
-          if (p.sched & 2) __builtin_nontemporal_store(val, dst);
+          v4f* dst = reinterpret_cast<v4f*>(s.c + static_cast<size_t>(row) * s.ldc + col);
+          if (sched & 2) __builtin_nontemporal_store(val, dst);
           else *dst = val;
         }
       }
@@ -735,20 +743,53 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         const int c = n0 + wn * WTN + tn * 16 + i16;
-        const float bs = (p.bias != nullptr && c < p.rb) ? p.bias[c] : 0.f;
+        const float bs = (s.bias != nullptr && c < s.rb) ? s.bias[c] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = row_base + 4 * q + r;
-          if (row < row_end && c < p.rb) {
-            const size_t off = static_cast<size_t>(row) * p.ldc + c;
+          if (row < row_end && c < s.rb) {
+            const size_t off = static_cast<size_t>(row) * s.ldc + c;
             float val = acc[tm][tn][r] + bs;
-            if (p.relu) val = fmaxf(val, 0.f);
-            if (p.mask != nullptr) val = p.mask[off] > 0.f ? val : 0.f;
-            p.c[off] = val;
+            if (s.relu) val = fmaxf(val, 0.f);
+            if (s.mask != nullptr) val = s.mask[off] > 0.f ? val : 0.f;
+            s.c[off] = val;
           }
         }
       }
     }
+  }
+}
+
+template <int WM, int WN, int DEPTH, class Probe = NoProbe>
+__global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_kernel(const GemmArgs p) {
+  constexpr int WTN = kC240 / WN;
+  static_assert((kR240 / WM) % 16 == 0 && WTN % 16 == 0 && WTN % 4 == 0 && (WM * WN) % 4 == 0, "wave tiles are whole 16x16 tiles");
+  __shared__ float lds[WM * WN * 16 * (WTN + 4)];   // epilogue patches only
+  const int m0 = blockIdx.x * kR240, n0 = blockIdx.y * kC240;
+  const int row_end = min(p.ra, m0 + kR240);
+  Probe::mark(0);
+  Probe::mark(1);
+  PanelStage s0{};
+  s0.a[0] = p.a[0], s0.a[1] = p.a[1], s0.b[0] = p.b[0], s0.b[1] = p.b[1];
+  s0.lda[0] = p.lda[0], s0.lda[1] = p.lda[1], s0.ldb[0] = p.ldb[0], s0.ldb[1] = p.ldb[1];
+  s0.kseg[0] = p.kseg[0], s0.kseg[1] = p.kseg[1];
+  s0.rb = p.rb, s0.ldc = p.ldc, s0.relu = p.relu, s0.c = p.c, s0.bias = p.bias, s0.mask = p.mask;
+  panel_stage<WM, WN, DEPTH>(s0, lds, p.sched, m0, n0, row_end);
+  Probe::mark(2);
+  // With c2 set a second GEMM follows in the same launch: the rows this workgroup has just stored are
+  // its A operand (the next layer's fc_pool behind fc_self + fc_neigh; the next input gradient behind
+  // this one) — one launch, one cold start and one output burst less per layer, and the operand
+  // comes back out of this CU's own L2 slice.
+  if (p.c2 != nullptr) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's rows of c are in memory ...
+    __threadfence_block();
+    __syncthreads();                       // ... and so are every other wave's, before any is read back
+    PanelStage s1{};
+    s1.a[0] = p.c, s1.a[1] = p.c, s1.b[0] = p.b2, s1.b[1] = p.b2;
+    s1.lda[0] = s1.lda[1] = p.ldc, s1.ldb[0] = s1.ldb[1] = p.ldb2;
+    s1.kseg[0] = p.rb, s1.kseg[1] = 0;
+    s1.rb = p.rb2, s1.ldc = p.ldc2, s1.relu = p.relu2, s1.c = p.c2, s1.bias = p.bias2, s1.mask = nullptr;
+    panel_stage<WM, WN, DEPTH>(s1, lds, p.sched, m0, 0, row_end);
   }
   Probe::mark(3);
 }
@@ -1217,10 +1258,9 @@ int launch_tiles(const GemmArgs& p, int grid_y_mult, int splits, hipStream_t st)
 }
 
 template <bool AKC, bool BKC>
-int launch_plain(const GemmArgs& p, hipStream_t st) {
-  if (p.rb <= 64) return launch_tiles<128, 64, 2, 2, AKC, BKC>(p, 1, 1, st);
-  if (p.rb <= 128) return launch_tiles<128, 128, 2, 2, AKC, BKC>(p, 1, 1, st);
+int pick_plain_variant(const GemmArgs& p) {
   int variant = BKC ? g_fwd_variant : g_igrad_variant;
+  if (p.rb <= 128 && variant < 9) return 0;   // narrow outputs: the 128 x 64 / 128 x 128 tiles (unless a panel kernel is forced)
   const bool row_count_invariant = variant == -2;   // automatic, but only 32x32x2 tiles: one reduction order
   if (variant < 0) {
     const int64_t cols = (p.rb + 255) / 256;
@@ -1233,12 +1273,33 @@ int launch_plain(const GemmArgs& p, hipStream_t st) {
       if (variant == 8 && rows240 < rows256 && !row_count_invariant) variant = 10;
     }
   }
+  return variant;
+}
+
+template <bool AKC, bool BKC>
+int launch_plain(const GemmArgs& p, hipStream_t st) {
+  const int variant = pick_plain_variant<AKC, BKC>(p);
   if constexpr (AKC && BKC) {
+    if (p.c2 != nullptr && !(variant == 10 && p.rb <= kC240 && p.rb2 <= kC240)) {
+      // not a one-panel-per-row-block launch: the chained GEMM runs as a launch of its own
+      GemmArgs first = p, next{};
+      first.c2 = nullptr;
+      int rc = launch_plain<true, true>(first, st);
+      if (rc != GTS_OK) return rc;
+      next.a[0] = next.a[1] = p.c, next.b[0] = next.b[1] = p.b2;
+      next.lda[0] = next.lda[1] = p.ldc, next.ldb[0] = next.ldb[1] = p.ldb2;
+      next.kseg[0] = p.rb, next.kseg[1] = 0;
+      next.ra = p.ra, next.rb = p.rb2, next.c = p.c2, next.ldc = p.ldc2, next.bias = p.bias2, next.relu = p.relu2;
+      next.tiles_per_split = (p.rb + kBK - 1) / kBK;
+      return launch_plain<true, true>(next, st);
+    }
     if (variant == 9) return launch_rows240(p, st);
     if (variant == 10) return launch_panel_direct<3, 4, 1>(p, st);
     if (variant == 11) return launch_panel_direct<1, 4, 1>(p, st);
     if (variant == 12) return launch_panel_direct<1, 4, 2>(p, st);
   }
+  if (p.rb <= 64) return launch_tiles<128, 64, 2, 2, AKC, BKC>(p, 1, 1, st);
+  if (p.rb <= 128) return launch_tiles<128, 128, 2, 2, AKC, BKC>(p, 1, 1, st);
   switch (variant) {
     // the variants that survived the sweeps in profiles/r01_tune_gemm.log (numbers kept from there)
     case 3: return launch_tiles<64, 256, 2, 4, AKC, BKC>(p, 1, 1, st);
@@ -1354,6 +1415,52 @@ extern "C" int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const fl
   p.ra = static_cast<int>(m), p.rb = static_cast<int>(n), p.c = out, p.ldc = static_cast<int>(n);
   p.bias = bias, p.relu = relu;
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
+  return launch_plain<true, true>(p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t gts_linear_fwd_chain_f32(const float* a0, const float* w0, const float* a1,
+                                            const float* w1, const float* bias, float* out,
+                                            const float* w2, const float* bias2, float* out2, int64_t m,
+                                            int64_t n, int64_t k0, int64_t k1, int32_t relu, int64_t n2,
+                                            int32_t relu2, void* stream) {
+  using namespace gts;
+  if (!a0 || !w0 || !out || !w2 || !out2 || ((a1 == nullptr) != (w1 == nullptr))) return GTS_ERR_NULL;
+  if (m < 0 || n <= 0 || n2 <= 0 || k0 <= 0 || k1 < 0 || m >= (1LL << 31) || n >= (1 << 20) || n2 >= (1 << 20) ||
+      k0 >= (1 << 20) || k1 >= (1 << 20) || !aligned4(k0) || !aligned4(k1) || !aligned4(n) || (a1 && k1 == 0))
+    return GTS_ERR_SHAPE;
+  if (m == 0) return GTS_OK;
+  GemmArgs p{};
+  p.a[0] = a0, p.b[0] = w0, p.lda[0] = static_cast<int>(k0), p.ldb[0] = static_cast<int>(k0);
+  p.kseg[0] = static_cast<int>(k0);
+  p.a[1] = a1 ? a1 : a0, p.b[1] = w1 ? w1 : w0;
+  p.lda[1] = p.ldb[1] = static_cast<int>(k1), p.kseg[1] = a1 ? static_cast<int>(k1) : 0;
+  p.ra = static_cast<int>(m), p.rb = static_cast<int>(n), p.c = out, p.ldc = static_cast<int>(n);
+  p.bias = bias, p.relu = relu;
+  p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
+  p.b2 = w2, p.bias2 = bias2, p.c2 = out2, p.rb2 = static_cast<int>(n2), p.ldb2 = static_cast<int>(n);
+  p.ldc2 = static_cast<int>(n2), p.relu2 = relu2;
+  return launch_plain<true, true>(p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t gts_linear_bwd_input_chain_t_f32(const float* g0, const float* w0t, const float* g1,
+                                                    const float* w1t, const float* relu_mask, float* gin,
+                                                    const float* w2t, float* gin2, int64_t m, int64_t k,
+                                                    int64_t n0, int64_t n1, int64_t k2, void* stream) {
+  using namespace gts;
+  if (!g0 || !w0t || !gin || !w2t || !gin2 || ((g1 == nullptr) != (w1t == nullptr))) return GTS_ERR_NULL;
+  if (m < 0 || k <= 0 || k2 <= 0 || n0 <= 0 || n1 < 0 || m >= (1LL << 31) || k >= (1 << 20) || k2 >= (1 << 20) ||
+      n0 >= (1 << 20) || n1 >= (1 << 20) || !aligned4(k) || !aligned4(n0) || !aligned4(n1) || (g1 && n1 == 0))
+    return GTS_ERR_SHAPE;
+  if (m == 0) return GTS_OK;
+  GemmArgs p{};
+  p.a[0] = g0, p.b[0] = w0t, p.lda[0] = p.ldb[0] = static_cast<int>(n0), p.kseg[0] = static_cast<int>(n0);
+  p.a[1] = g1 ? g1 : g0, p.b[1] = w1t ? w1t : w0t;
+  p.lda[1] = p.ldb[1] = static_cast<int>(n1), p.kseg[1] = g1 ? static_cast<int>(n1) : 0;
+  p.ra = static_cast<int>(m), p.rb = static_cast<int>(k), p.c = gin, p.ldc = static_cast<int>(k);
+  p.mask = relu_mask;
+  p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
+  p.b2 = w2t, p.bias2 = nullptr, p.c2 = gin2, p.rb2 = static_cast<int>(k2), p.ldb2 = static_cast<int>(k);
+  p.ldc2 = static_cast<int>(k2), p.relu2 = 0;
   return launch_plain<true, true>(p, static_cast<hipStream_t>(stream));
 }
 

@@ -115,6 +115,64 @@ def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False):
     return out
 
 
+def linear_fwd_chain(a0, w0, a1, w1, bias, relu, w2, bias2, relu2):
+    """(out, out2) with out = act(a0 @ w0^T [+ a1 @ w1^T] + bias) and out2 = act2(out @ w2^T + bias2): the two
+    GEMMs of consecutive layers in ONE launch when the operands are tall and at most 256 wide (the workgroup
+    that has produced a row panel of `out` multiplies it on), otherwise two launches — same values either way.
+    All widths must be multiples of 4 (no padding here: callers fall back to two linear_fwd calls)."""
+    _same(_mat(a0, "a0").shape[1], _mat(w0, "w0").shape[1], "inner dims of a0 @ w0^T")
+    if (a1 is None) != (w1 is None):
+        raise _lib.GtsError("a1 and w1 go together")
+    if a1 is not None:
+        _same(_mat(a1, "a1").shape[1], _mat(w1, "w1").shape[1], "inner dims of a1 @ w1^T")
+        _same(a1.shape[0], a0.shape[0], "rows of a0 / a1")
+        _same(w1.shape[0], w0.shape[0], "rows of w0 / w1")
+    m, n, n2 = a0.shape[0], w0.shape[0], w2.shape[0]
+    _same(_mat(w2, "w2").shape[1], n, "inner dims of out @ w2^T")
+    if bias is not None:
+        _same(tuple(bias.shape), (n,), "bias vs output columns")
+    if bias2 is not None:
+        _same(tuple(bias2.shape), (n2,), "bias2 vs output columns")
+    k0, k1 = a0.shape[1], a1.shape[1] if a1 is not None else 0
+    if n % 4 or k0 % 4 or k1 % 4:
+        raise _lib.GtsError("linear_fwd_chain needs widths that are multiples of 4")
+    dev = _chk(a0, w0, a1, w1, bias, w2, bias2)
+    out = torch.empty((m, n), dtype=torch.float32, device=dev)
+    out2 = torch.empty((m, n2), dtype=torch.float32, device=dev)
+    _timed("fwd", 2.0 * m * n * (k0 + k1) + 2.0 * m * n2 * n, lambda: check(
+        _lib.load().gts_linear_fwd_chain_f32(ptr(a0), ptr(w0), ptr(a1), ptr(w1), ptr(bias), ptr(out), ptr(w2),
+                                             ptr(bias2), ptr(out2), m, n, k0, k1, 1 if relu else 0, n2,
+                                             1 if relu2 else 0, current_stream()), "gts_linear_fwd_chain_f32"))
+    return out, out2
+
+
+def linear_bwd_input_chain_t(g0, w0t, g1, w1t, relu_mask, w2t):
+    """(gin, gin2) with gin = (g0 @ w0 [+ g1 @ w1]) (zeroed where relu_mask <= 0) and gin2 = gin @ w2, from
+    TRANSPOSED weights (w0t [K,N0], w1t [K,N1], w2t [K2,K]); one launch under the conditions of linear_fwd_chain."""
+    _same(_mat(g0, "g0").shape[1], _mat(w0t, "w0t").shape[1], "inner dims of g0 @ w0t^T")
+    if (g1 is None) != (w1t is None):
+        raise _lib.GtsError("g1 and w1t go together")
+    if g1 is not None:
+        _same(_mat(g1, "g1").shape[1], _mat(w1t, "w1t").shape[1], "inner dims of g1 @ w1t^T")
+        _same(g1.shape[0], g0.shape[0], "rows of g0 / g1")
+        _same(w1t.shape[0], w0t.shape[0], "rows of w0t / w1t")
+    m, k, k2 = g0.shape[0], w0t.shape[0], w2t.shape[0]
+    _same(_mat(w2t, "w2t").shape[1], k, "inner dims of gin @ w2t^T")
+    if relu_mask is not None:
+        _same(tuple(relu_mask.shape), (m, k), "relu_mask vs result")
+    n0, n1 = g0.shape[1], g1.shape[1] if g1 is not None else 0
+    if k % 4 or n0 % 4 or n1 % 4:
+        raise _lib.GtsError("linear_bwd_input_chain_t needs widths that are multiples of 4")
+    dev = _chk(g0, w0t, g1, w1t, relu_mask, w2t)
+    gin = torch.empty((m, k), dtype=torch.float32, device=dev)
+    gin2 = torch.empty((m, k2), dtype=torch.float32, device=dev)
+    _timed("igrad", 2.0 * m * k * (n0 + n1) + 2.0 * m * k2 * k, lambda: check(
+        _lib.load().gts_linear_bwd_input_chain_t_f32(ptr(g0), ptr(w0t), ptr(g1), ptr(w1t), ptr(relu_mask), ptr(gin),
+                                                     ptr(w2t), ptr(gin2), m, k, n0, n1, k2, current_stream()),
+        "gts_linear_bwd_input_chain_t_f32"))
+    return gin, gin2
+
+
 def linear_bwd_input(g0, w0, g1=None, w1=None, relu_mask=None):
     """g0 @ w0 [+ g1 @ w1].  g [M,N], w [N,K] -> [M,K]; zeroed where relu_mask [M,K] <= 0."""
     _same(_mat(g0, "g0").shape[1], _mat(w0, "w0").shape[0], "inner dims of g0 @ w0")

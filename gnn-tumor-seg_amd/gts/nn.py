@@ -77,6 +77,16 @@ def _side_stream(device):
     return s
 
 
+# GTS_CHAIN_GEMMS=0 keeps one launch per GEMM in the fused stack (A/B runs).
+CHAIN_LAYER_GEMMS = os.environ.get("GTS_CHAIN_GEMMS", "1") != "0"
+
+
+def _chainable(a0, w0, a1, w2):
+    """Shapes the chained launch takes: every width a multiple of 4, the intermediate at most 256 wide."""
+    n, k0, k1, n2 = w0.shape[0], a0.shape[1], a1.shape[1], w2.shape[0]
+    return n % 4 == 0 and k0 % 4 == 0 and k1 % 4 == 0 and n <= 256 and n2 <= 256 and w2.shape[1] == n
+
+
 def _pool_layer_weight_grads(g, gp, h, m, w_pool, w_self):
     """(g_ws, g_wn, g_wp, g_bias, g_bp) of one pool layer; one launch when Fin == Fout."""
     if w_pool.shape == w_self.shape:
@@ -101,12 +111,20 @@ class _SagePoolStack(torch.autograd.Function):
         n_layers = len(params) // 5
         h = x.contiguous()
         saved = []
+        p = None                          # relu(fc_pool(h)) of the layer about to run, when already computed
         for i in range(n_layers):
             w_pool, b_pool, w_self, w_neigh, bias = params[5 * i:5 * i + 5]
             last = i == n_layers - 1
-            p = dense.linear_fwd(h, w_pool, bias=b_pool, relu=True)
+            if p is None:
+                p = dense.linear_fwd(h, w_pool, bias=b_pool, relu=True)
             m, arg = ops.spmm_max_fwd(g, p, want_arg=need_bwd, relu_input=True)   # p is not kept
-            out = dense.linear_fwd(h, w_self, m, w_neigh, bias=bias, relu=not last)
+            p = None
+            nxt = params[5 * (i + 1):5 * (i + 1) + 2] if not last else None
+            if CHAIN_LAYER_GEMMS and nxt is not None and _chainable(h, w_self, m, nxt[0]):
+                # fc_self + fc_neigh of this layer and fc_pool of the next one in one launch
+                out, p = dense.linear_fwd_chain(h, w_self, m, w_neigh, bias, True, nxt[0], nxt[1], True)
+            else:
+                out = dense.linear_fwd(h, w_self, m, w_neigh, bias=bias, relu=not last)
             saved += [h, m, arg]
             h = out
         if need_bwd:
@@ -156,11 +174,14 @@ class _SagePoolStack(torch.autograd.Function):
             key = (grad_out.shape[1], act.shape[1])
             deferred.setdefault(key, []).append((grad_out, act, bias_slot is not None, slot, bias_slot))
 
+        gm = None                         # g @ W_neigh of the layer about to run, when already computed
         for i in reversed(range(n)):
             h, m, arg = acts[3 * i:3 * i + 3]
             w_pool, _b_pool, w_self, w_neigh, _bias = params[5 * i:5 * i + 5]
-            gm = igrad(g, w_neigh)
+            if gm is None:
+                gm = igrad(g, w_neigh)
             gp = ops.spmm_max_bwd(ctx.g, gm, arg)       # ReLU'(p) is already in the winner record
+            gm = None
             if side is None:
                 defer(gp, h, 5 * i, 5 * i + 1)          # fc_pool.weight, fc_pool.bias
                 defer(g, h, 5 * i + 2, 5 * i + 4)       # fc_self.weight, bias
@@ -174,7 +195,14 @@ class _SagePoolStack(torch.autograd.Function):
                 keep_alive.append((g, gp))              # still being read by the side stream
                 grads[5 * i:5 * i + 5] = [g_wp, g_bp, g_ws, g_wn, g_bias]
             if i > 0:      # h is layer i-1's ReLU output: its backward is the mask h > 0
-                g = igrad(g, w_self, gp, w_pool, relu_mask=h)
+                below = params[5 * (i - 1) + 3]          # W_neigh of the layer below
+                if CHAIN_LAYER_GEMMS and all(id(w) in turned for w in (w_self, w_pool, below)) \
+                        and _chainable(g, w_self.t(), gp, below.t()):
+                    # this layer's input gradient and the next one's g @ W_neigh in one launch
+                    g, gm = dense.linear_bwd_input_chain_t(g, turned[id(w_self)], gp, turned[id(w_pool)], h,
+                                                           turned[id(below)])
+                else:
+                    g = igrad(g, w_self, gp, w_pool, relu_mask=h)
             elif ctx.needs_input_grad[1]:
                 gx = igrad(g, w_self, gp, w_pool)
         for problems in deferred.values():

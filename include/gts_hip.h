@@ -217,6 +217,20 @@ int32_t gts_linear_bwd_input_f32(const float* g0, const float* w0, const float* 
 int32_t gts_linear_bwd_input_t_f32(const float* g0, const float* w0t, const float* g1, const float* w1t,
                                    const float* relu_mask, float* gin, int64_t m, int64_t k,
                                    int64_t n0, int64_t n1, void* stream);
+/* two GEMMs of a layer chain in one call (one launch when the operands are tall and <= 256 wide, otherwise two):
+ *   out  [m, n]  = act (a0 w0^T (+ a1 w1^T) + bias)          exactly gts_linear_fwd_f32
+ *   out2 [m, n2] = act2(out w2^T + bias2)                      exactly gts_linear_fwd_f32 on `out`
+ * (SAGEConv-pool stack: fc_self + fc_neigh of layer L, then fc_pool of layer L+1 on the rows just produced).
+ * The input-gradient form chains  gin = (g0 w0 (+ g1 w1)) (. mask)  and  gin2 = gin w2  on transposed weights
+ * (w0t [k, n0], w1t [k, n1], w2t [k2, k]).  n (resp. k) must be a multiple of 4. */
+int32_t gts_linear_fwd_chain_f32(const float* a0, const float* w0, const float* a1, const float* w1,
+                                 const float* bias, float* out, const float* w2, const float* bias2,
+                                 float* out2, int64_t m, int64_t n, int64_t k0, int64_t k1, int32_t relu,
+                                 int64_t n2, int32_t relu2, void* stream);
+int32_t gts_linear_bwd_input_chain_t_f32(const float* g0, const float* w0t, const float* g1,
+                                         const float* w1t, const float* relu_mask, float* gin,
+                                         const float* w2t, float* gin2, int64_t m, int64_t k, int64_t n0,
+                                         int64_t n1, int64_t k2, void* stream);
 /* dst[q][c, r] = src[q][r, c] for n_mats matrices of one shape [rows, cols] in one launch per 32
  * (src, dst: HOST arrays of device pointers).  Serves the transposed-weight form above: the
  * weights of a layer stack (torch Linear layout [out, in]) are turned once per backward pass. */

@@ -278,3 +278,27 @@ def test_direct_fragment_weight_gradient_against_fp64(hip_lib, m, k, n, count, v
         if gb is not None:
             _check(gb, g.double().sum(0), g.double().abs().sum(0))
         assert torch.equal(gw, again[q][0])
+
+
+@pytest.mark.parametrize("m,k0,k1,n,n2", [(60000, 256, 256, 256, 256), (60000, 4, 4, 256, 256), (49999, 132, 0, 256, 64),
+                                          (60000, 256, 0, 132, 4), (1000, 64, 64, 256, 256), (120000, 256, 256, 256, 256)])
+def test_chained_layer_gemms_equal_two_calls_bit_for_bit(m, k0, k1, n, n2):
+    """gts_linear_fwd_chain_f32 / gts_linear_bwd_input_chain_t_f32: the second GEMM computed by the workgroup that
+    has just stored those rows (one launch at the tall shapes, two at m = 1000) gives the bits of two separate calls."""
+    a0, w0 = _rand(m, k0, seed=1).to(DEV), _rand(n, k0, seed=2).to(DEV)
+    a1, w1 = (_rand(m, k1, seed=3).to(DEV), _rand(n, k1, seed=4).to(DEV)) if k1 else (None, None)
+    b, w2, b2 = _rand(n, seed=5).to(DEV), _rand(n2, n, seed=6).to(DEV), _rand(n2, seed=7).to(DEV)
+    out, out2 = dense.linear_fwd_chain(a0, w0, a1, w1, b, True, w2, b2, True)
+    want = dense.linear_fwd(a0, w0, a1, w1, bias=b, relu=True)
+    want2 = dense.linear_fwd(want, w2, bias=b2, relu=True)
+    assert torch.equal(out, want) and torch.equal(out2, want2)
+    ref = a0.cpu().double() @ w0.cpu().double().t() + b.cpu().double()
+    if k1:
+        ref += a1.cpu().double() @ w1.cpu().double().t()
+    ref2 = (ref.clamp(min=0) @ w2.cpu().double().t() + b2.cpu().double()).clamp(min=0)
+    assert torch.allclose(out2.cpu().double(), ref2, rtol=1e-4, atol=1e-4 * float(ref2.abs().max()))
+    # input-gradient form on transposed weights, with the ReLU mask between the two products
+    mask = _rand(m, n, seed=8).to(DEV)
+    gin, gin2 = dense.linear_bwd_input_chain_t(a0, w0, a1, w1, mask, w2)
+    want = dense.linear_bwd_input_t(a0, w0, a1, w1, relu_mask=mask)
+    assert torch.equal(gin, want) and torch.equal(gin2, dense.linear_bwd_input_t(want, w2))
