@@ -1280,8 +1280,9 @@ template <bool AKC, bool BKC>
 int launch_plain(const GemmArgs& p, hipStream_t st) {
   const int variant = pick_plain_variant<AKC, BKC>(p);
   if constexpr (AKC && BKC) {
-    if (p.c2 != nullptr && !(variant == 10 && p.rb <= kC240 && p.rb2 <= kC240)) {
-      // not a one-panel-per-row-block launch: the chained GEMM runs as a launch of its own
+    if (p.c2 != nullptr && !(variant == 10 && p.rb <= kC240 && p.rb2 <= kC240 && p.rb2 > 128)) {
+      // not a one-panel-per-row-block launch (or a narrow second output, which a launch of its own
+      // would give to the 32x32x2 tiles): the chained GEMM runs as a launch of its own — same bits either way
       GemmArgs first = p, next{};
       first.c2 = nullptr;
       int rc = launch_plain<true, true>(first, st);

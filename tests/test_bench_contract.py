@@ -46,7 +46,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields(hip_lib):
     r = d["roofline"]                                        # the dominant kernel: K11
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and 0 < r["frac"] < 1
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] is None
-    assert set(r["by_kind"]) == {"fwd", "igrad", "wgrad"} and r["by_kind"]["fwd"]["launches_per_step"] == 16
+    # 8 layers: fc_pool of layer 0, seven chained launches (fc_self + fc_neigh of layer L, fc_pool of L+1), the last pair
+    assert set(r["by_kind"]) == {"fwd", "igrad", "wgrad"} and r["by_kind"]["fwd"]["launches_per_step"] == 9
+    assert r["by_kind"]["igrad"]["launches_per_step"] == 9
     names = [h["kernel"] for h in d["roofline_hbm"]]
     assert names == ["spmm_max_fwd_f256", "spmm_max_bwd_f256"]
     for h in d["roofline_hbm"]:
