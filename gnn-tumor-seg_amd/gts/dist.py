@@ -20,7 +20,6 @@ import os
 
 import torch
 import torch.distributed as dist
-import torch.nn.functional as F
 
 
 # bench.py installs a callable here (launch -> result) to bracket the gradient all-reduce with HIP
@@ -134,15 +133,17 @@ class FlatGradSync:
         for p in self.params:
             p.grad = None
 
-    def weighted_ce_backward(self, logits, labels, class_weights):
-        """Back-propagate the local numerator and keep (denominator, numerator) for the exchange."""
-        if logits.is_cuda:      # fused HIP pass: numerator (with gradient) + denominator at once
+    def weighted_ce_backward(self, logits, labels, class_weights, cross_entropy_sum=None):
+        """Back-propagate the local numerator and keep (denominator, numerator) for the exchange.
+        The loss is the fused HIP pass (numerator with gradient + denominator at once); there is no
+        CPU path here — the gloo tests, which drive this class with the oracle network on the CPU,
+        inject theirs through `cross_entropy_sum(logits, labels, class_weights) -> (num, den)`."""
+        if cross_entropy_sum is not None:
+            num, den = cross_entropy_sum(logits, labels, class_weights)
+        else:
             from . import ops
             num, stats = ops.weighted_cross_entropy_stats(logits, labels, class_weights)
             den = stats[1]
-        else:                   # CPU rehearsal (gloo tests drive this class with the oracle net)
-            num = F.cross_entropy(logits, labels, weight=class_weights, reduction="sum")
-            den = class_weights[labels].sum()
         num.backward()
         self._scalars = torch.stack([den.detach(), num.detach()])
 

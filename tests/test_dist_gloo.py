@@ -46,6 +46,12 @@ def _batch(samples):
         torch.from_numpy(np.concatenate([s[2] for s in samples]))
 
 
+def _oracle_ce(logits, labels, w):
+    """(numerator, denominator) of the class-weighted CE on the CPU — the loss the gloo tests inject into
+    FlatGradSync (the product's own loss is a HIP kernel)."""
+    return F.cross_entropy(logits, labels, weight=w, reduction="sum"), w[labels].sum()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -64,7 +70,7 @@ def _worker(rank, world, port, n_graphs, out_dir):
     mine = gdist.shard_indices(list(range(n_graphs)), 0, n_graphs // world, rank, world)
     g, x, y = _batch([samples[i] for i in mine])
     sync.zero_grad()
-    sync.weighted_ce_backward(net(g, x), y, torch.tensor(W))
+    sync.weighted_ce_backward(net(g, x), y, torch.tensor(W), _oracle_ce)
     loss = sync.all_reduce_and_normalise()
     torch.save({"loss": float(loss), "grads": [p.grad.clone() for p in net.parameters()], "mine": mine},
                os.path.join(out_dir, f"rank{rank}.pt"))
@@ -105,7 +111,7 @@ def test_single_process_sync_is_identity():
     sync = gdist.FlatGradSync(net.parameters())
     g, x, y = _batch(_samples(3))
     sync.zero_grad()
-    sync.weighted_ce_backward(net(g, x), y, torch.tensor(W))
+    sync.weighted_ce_backward(net(g, x), y, torch.tensor(W), _oracle_ce)
     loss = sync.all_reduce_and_normalise()
     flat_ptr = sync.flat.data_ptr()
     ref = _net()
@@ -169,7 +175,7 @@ def _epoch_worker(rank, world, port, n_samples, per_rank, out_dir):
             ids, g, feats, labels = item
             seen += ids
             sync.zero_grad()
-            sync.weighted_ce_backward(net(_tgraph_of(g), feats), labels, torch.tensor(W))
+            sync.weighted_ce_backward(net(_tgraph_of(g), feats), labels, torch.tensor(W), _oracle_ce)
         losses.append(float(sync.all_reduce_and_normalise()))
         opt.step()
     torch.save({"hp": tuple(map(str, hp)), "own": tuple(map(str, own)), "refused": refused, "seen": seen,
