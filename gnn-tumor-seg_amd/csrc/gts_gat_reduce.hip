@@ -1,6 +1,7 @@
 // GATConv backward: the column reductions over the node axis, fused with the elementwise work
 // that produces their inputs (HBM-bound, one pass over each [N, H*D] tensor):
-//   gat_act_bwd      g_pre = gout * act'(out)  (ELU through its output)  +  bias grad = colsum(g_pre)
+//   gat_act_bwd      g_pre = gout * act'(out)  (ELU or ReLU through its output)  +  bias grad = colsum(g_pre)
+//                    (also the ReLU / bias backward of the SAGEConv mean / gcn layers)
 //   gat_param_grad   g_attn_l[h,:] = sum_n gel[n,h] ft[n,h,:],  g_attn_r likewise with ger
 // Both walk row chunks with one 16-byte column group per thread (256 threads x 16 B = one 4 KiB
 // row of the 1024-wide C3 layers per iteration), keep per-chunk partial sums in registers, write
@@ -30,10 +31,10 @@ __global__ __launch_bounds__(kBlock) void gat_act_bwd_kernel(
     for (int64_t row = row0; row < row1; ++row) {
       const size_t off = static_cast<size_t>(row) * cols + 4 * q;
       v4f g = *reinterpret_cast<const v4f*>(gout + off);
-      if (act == 1) {  // ELU: d/dx = 1 for x > 0, exp(x) = out + 1 otherwise
+      if (act != 0) {  // ELU: d/dx = 1 for x > 0, exp(x) = out + 1 otherwise; ReLU (2): 1 for out > 0, else 0
         const v4f o = *reinterpret_cast<const v4f*>(out + off);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : g[e] * (o[e] + 1.0f);
+        for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : (act == 1 ? g[e] * (o[e] + 1.0f) : 0.0f);
         *reinterpret_cast<v4f*>(g_pre + off) = g;
       }
       acc += g;
@@ -108,9 +109,9 @@ extern "C" int32_t gts_gat_act_bwd_f32(const float* gout, const float* out, int3
                                        int64_t workspace_bytes, int64_t n, int64_t cols,
                                        void* stream) {
   using namespace gts;
-  if (!gout || (activation == 1 && (!out || !g_pre)) || (g_bias && !workspace)) return GTS_ERR_NULL;
+  if (!gout || (activation != 0 && (!out || !g_pre)) || (g_bias && !workspace)) return GTS_ERR_NULL;
   if (bad(n, cols)) return GTS_ERR_SHAPE;
-  if (activation != 0 && activation != 1) return GTS_ERR_ARGKIND;
+  if (activation < 0 || activation > 2) return GTS_ERR_ARGKIND;
   if (g_bias && workspace_bytes < gts_gat_reduce_workspace(n, cols) / 2) return GTS_ERR_SHAPE;
   if (activation == 0 && !g_bias) return GTS_OK;  // nothing to do
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -181,7 +181,8 @@ template <int VEC, int LPR, bool DIV_IN>
 __global__ __launch_bounds__(kBlock) void spmm_sum_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const float* __restrict__ x, float* __restrict__ out, const float* __restrict__ div_in,
-    const float* __restrict__ div_out, int add_self, int n_out, int n_feat, int seq) {
+    const float* __restrict__ div_out, const float* __restrict__ accum, int add_self, int n_out, int n_feat,
+    int seq) {
   for (int s = 0; s < seq; ++s) {
     const int v = owned_row<LPR>(s, seq, n_out);
     if (v < 0) continue;
@@ -220,6 +221,11 @@ __global__ __launch_bounds__(kBlock) void spmm_sum_kernel(
       const float dv = div_out != nullptr ? div_out[v] : 1.0f;
 #pragma unroll
       for (int t = 0; t < VEC; ++t) o.v[t] = div_out != nullptr ? acc[t] / dv : acc[t];
+      if (accum != nullptr) {   // the gradient that reached this row by another path (fc_self beside the neighbour term)
+        const Vec<VEC> other = Vec<VEC>::load(accum + off);
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) o.v[t] = other.v[t] + o.v[t];
+      }
       if (active) o.store(out + off);
     });
   }
@@ -277,8 +283,8 @@ extern "C" int32_t gts_spmm_max_bwd_f32(const int32_t* t_indptr, const int32_t* 
 
 extern "C" int32_t gts_spmm_sum_f32(const int32_t* indptr, const int32_t* indices,
                                     const float* x, float* out, const float* div_in,
-                                    const float* div_out, int32_t add_self, int64_t n_out,
-                                    int64_t n_feat, void* stream) {
+                                    const float* div_out, const float* accum, int32_t add_self,
+                                    int64_t n_out, int64_t n_feat, void* stream) {
   using namespace gts;
   if (!indptr || !x || !out) return GTS_ERR_NULL;
   if (bad_shape(n_out, n_feat)) return GTS_ERR_SHAPE;
@@ -288,9 +294,9 @@ extern "C" int32_t gts_spmm_sum_f32(const int32_t* indptr, const int32_t* indice
   const int no = static_cast<int>(n_out), nf = static_cast<int>(n_feat);
   GTS_DISPATCH_GEOM(g, {
     if (div_in != nullptr)
-      spmm_sum_kernel<VEC, LPR, true><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, div_in, div_out, add_self, no, nf, g.seq);
+      spmm_sum_kernel<VEC, LPR, true><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, div_in, div_out, accum, add_self, no, nf, g.seq);
     else
-      spmm_sum_kernel<VEC, LPR, false><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, div_in, div_out, add_self, no, nf, g.seq);
+      spmm_sum_kernel<VEC, LPR, false><<<g.grid, kBlock, 0, st>>>(indptr, indices, x, out, div_in, div_out, accum, add_self, no, nf, g.seq);
   })
   return launch_status();
 }

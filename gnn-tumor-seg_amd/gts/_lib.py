@@ -10,7 +10,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgts_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "gts_hip.h")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -24,7 +24,7 @@ SIGNATURES = {
     "gts_error_string": [_i32],
     "gts_spmm_max_fwd_f32": [_p, _p, _p, _p, _p, _i32, _i32, _i64, _i64, _p],
     "gts_spmm_max_bwd_f32": [_p, _p, _p, _p, _p, _i32, _p, _p, _i64, _i64, _p],
-    "gts_spmm_sum_f32": [_p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _p],
+    "gts_spmm_sum_f32": [_p, _p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _p],
     "gts_gat_fwd_f32": [_p, _p, _p, _p, _p, _f32, _p, _p, _i32, _p, _p, _i64, _i64, _i64, _p],
     "gts_gat_scores_f32": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     "gts_gat_reduce_workspace": [_i64, _i64],

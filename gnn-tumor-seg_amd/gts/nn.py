@@ -55,6 +55,83 @@ class _SagePoolLayer(torch.autograd.Function):
         return None, gh, g_wp, g_bp, g_ws, g_wn, g_bias, None, None
 
 
+class _SageSumLayer(torch.autograd.Function):
+    """SAGEConv 'mean' / 'gcn' as ONE autograd node (DGL semantics as in the oracle's R-mean / R-gcn / R-lin):
+
+        neigh = reduce_g(src)                                   K3/K4 (mean: / max(deg,1); gcn: (+self) / (deg+1))
+        out   = act( [fc_self(h) +] fc_neigh-term + bias )      one GEMM launch, bias and ReLU in its epilogue
+
+    where, when in_feats > out_feats, fc_neigh is applied BEFORE the aggregation (`lin_before_mp`) and the
+    aggregated [N, out] term enters the GEMM through an identity weight (x * 1 + 0 ... : exact).  The backward
+    runs the ReLU mask and the bias gradient in one pass (gts_gat_act_bwd_f32), the two weight gradients in one
+    launch, and adds the fc_self path inside the reducer (`accum`) — no elementwise torch kernels."""
+
+    @staticmethod
+    def forward(ctx, g, h, w_self, w_neigh, bias, mode, relu_out, need_bwd):
+        h = h.contiguous()
+        d = g.dev()
+        fin, fout = w_neigh.shape[1], w_neigh.shape[0]
+        lin_first = fin > fout
+        div = d.deg_clamped if mode == "mean" else d.deg_plus1
+        src = dense.linear_fwd(h, w_neigh) if lin_first else h
+        neigh = ops.spmm_sum_raw(g, src, div_out=div, add_self=(mode == "gcn"))
+        last_w = _identity(fout, h.device) if lin_first else w_neigh
+        if w_self is not None:
+            out = dense.linear_fwd(h, w_self, neigh, last_w, bias=bias, relu=relu_out)
+        else:
+            out = dense.linear_fwd(neigh, last_w, bias=bias, relu=relu_out)
+        if need_bwd:
+            ctx.g, ctx.mode, ctx.relu_out, ctx.lin_first = g, mode, relu_out, lin_first
+            ctx.has_bias = bias is not None
+            ctx.save_for_backward(h, neigh if not lin_first else None, out if relu_out else None, w_self, w_neigh)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        h, neigh, out, w_self, w_neigh = ctx.saved_tensors
+        g, mode = ctx.g, ctx.mode
+        d = g.dev()
+        div = d.deg_clamped if mode == "mean" else d.deg_plus1
+        need = ctx.needs_input_grad
+        g_pre, g_bias = ops.gat_act_bwd(gout.contiguous(), out, 2 if ctx.relu_out else 0, want_bias_grad=ctx.has_bias)
+
+        def reduce_bwd(t, accum=None):   # autograd of the reducer: the same sum over the out-CSR
+            return ops.spmm_sum_raw(g, t, transposed=True, div_in=div, add_self=(mode == "gcn"), accum=accum)
+
+        g_ws = None
+        if ctx.lin_first:
+            # out = fc_self(h) + reduce(fc_neigh(h)) + b: the gradient of the [N, out] neighbour term is
+            # reduce^T(g_pre); both weight matrices then multiply h
+            gt = reduce_bwd(g_pre)
+            if w_self is not None:
+                (g_ws, _), (g_wn, _) = dense.linear_bwd_weight_multi([(g_pre, h, False), (gt, h, False)])
+                gh = dense.linear_bwd_input(g_pre, w_self, gt, w_neigh) if need[1] else None
+            else:
+                g_wn, _ = dense.linear_bwd_weight(gt, h)
+                gh = dense.linear_bwd_input(gt, w_neigh) if need[1] else None
+        else:
+            if w_self is not None:
+                (g_ws, _), (g_wn, _) = dense.linear_bwd_weight_multi([(g_pre, h, False), (g_pre, neigh, False)])
+            else:
+                g_wn, _ = dense.linear_bwd_weight(g_pre, neigh)
+            gh = None
+            if need[1]:
+                gneigh = dense.linear_bwd_input(g_pre, w_neigh)
+                gself = dense.linear_bwd_input(g_pre, w_self) if w_self is not None else None
+                gh = reduce_bwd(gneigh, accum=gself)
+        return None, gh, g_ws, g_wn, g_bias, None, None, None
+
+
+_identities = {}
+
+
+def _identity(n, device):
+    key = (n, device)
+    if key not in _identities:
+        _identities[key] = torch.eye(n, dtype=torch.float32, device=device)
+    return _identities[key]
+
+
 # GTS_OVERLAP_WGRAD=1 runs the weight gradients of the fused stack on a second, low-priority stream
 # (see _SagePoolStack.backward).  Off by default: with the current kernels the side stream takes
 # CUs from the input-gradient chain it was meant to fill in behind (757 graphs/s with it, 777-789
@@ -294,7 +371,13 @@ class SAGEConv(nn.Module):
             rst = _SagePoolLayer.apply(graph, h, self.fc_pool.weight, self.fc_pool.bias,
                                        self.fc_self.weight, self.fc_neigh.weight, bias,
                                        fused_relu, need_bwd)
-        else:
+        elif self._out_feats % 4 == 0 and h.shape[0] > 0:
+            need_bwd = torch.is_grad_enabled() and (
+                h.requires_grad or any(p.requires_grad for p in self.parameters()))
+            w_self = self.fc_self.weight if self._aggre_type != "gcn" else None
+            rst = _SageSumLayer.apply(graph, h, w_self, self.fc_neigh.weight, self.bias, self._aggre_type,
+                                      fused_relu, need_bwd)
+        else:   # odd output widths (the fused node's kernels work on 16-byte column groups): op by op
             lin_before_mp = self._in_src_feats > self._out_feats
             src = dense.linear(h, self.fc_neigh.weight) if lin_before_mp else h
             neigh = ops.spmm_reduce(graph, src, self._aggre_type)

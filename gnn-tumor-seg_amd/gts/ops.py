@@ -84,11 +84,12 @@ def spmm_max_bwd(g, gout, arg, relu_src=None):
     return gx
 
 
-def spmm_sum_raw(g, x, transposed=False, div_in=None, div_out=None, add_self=False):
-    """K3/K4.  Generic sum reducer over the in-CSR (or the out-CSR when transposed)."""
+def spmm_sum_raw(g, x, transposed=False, div_in=None, div_out=None, add_self=False, accum=None):
+    """K3/K4.  Generic sum reducer over the in-CSR (or the out-CSR when transposed); `accum` [N,F] is added
+    to the result (a gradient that reached the rows by another path)."""
     x = x.contiguous()
-    _f32(x, div_in, div_out)
-    require_device(x, div_in, div_out)
+    _f32(x, div_in, div_out, accum)
+    require_device(x, div_in, div_out, accum)
     d = g.dev()
     indptr, indices = (d.t_indptr, d.t_indices) if transposed else (d.indptr, d.indices)
     n = g.n
@@ -97,9 +98,10 @@ def spmm_sum_raw(g, x, transposed=False, div_in=None, div_out=None, add_self=Fal
     f = x.shape[1]
     _expect(div_in, (n,), "div_in")
     _expect(div_out, (n,), "div_out")
+    _expect(accum, (n, f), "accum")
     out = torch.empty_like(x)
     check(_lib.load().gts_spmm_sum_f32(ptr(indptr), ptr(indices), ptr(x), ptr(out), ptr(div_in), ptr(div_out),
-                                       1 if add_self else 0, n, f, current_stream()), "gts_spmm_sum_f32")
+                                       ptr(accum), 1 if add_self else 0, n, f, current_stream()), "gts_spmm_sum_f32")
     return out
 
 
@@ -248,7 +250,8 @@ def _reduce_ws(n, cols, device):
 
 
 def gat_act_bwd(gout, out, activation, want_bias_grad):
-    """(g_pre, g_bias): g_pre = gout * act'(out) (ELU via its output), g_bias = g_pre.sum(0)."""
+    """(g_pre, g_bias): g_pre = gout * act'(out) (activation 1 = ELU, 2 = ReLU, through the output; 0 = none),
+    g_bias = g_pre.sum(0)."""
     gout = gout.contiguous()
     n, cols = gout.shape[0], gout[0].numel()
     if activation:

@@ -67,11 +67,12 @@ int32_t gts_spmm_max_bwd_f32(const int32_t* t_indptr, const int32_t* t_indices,
  * (model/networks.py:73,75 via :25-30) and, on the out-CSR, their autograd.
  *   s[v,f]   = sum_k  x[idx_k, f] / (div_in ? div_in[idx_k] : 1)   (slot order)
  *   if add_self: s[v,f] += x[v,f] / (div_in ? div_in[v] : 1)        (needs square graph)
- *   out[v,f] = s[v,f] / (div_out ? div_out[v] : 1)
+ *   out[v,f] = s[v,f] / (div_out ? div_out[v] : 1)   (+ accum[v,f] when accum is given: the gradient
+ *              that reached row v by another path, e.g. through fc_self beside the neighbour term)
  * mean fwd: div_out = max(deg,1); mean bwd: out-CSR, div_in = max(deg,1);
  * gcn  fwd: add_self, div_out = deg+1;  gcn bwd: out-CSR, add_self, div_in = deg+1. */
 int32_t gts_spmm_sum_f32(const int32_t* indptr, const int32_t* indices, const float* x,
-                         float* out, const float* div_in, const float* div_out,
+                         float* out, const float* div_in, const float* div_out, const float* accum,
                          int32_t add_self, int64_t n_out, int64_t n_feat, void* stream);
 
 /* ---- K5-K7: GATConv attention + aggregation (forward) -------------------------------
@@ -92,7 +93,7 @@ int32_t gts_gat_scores_f32(const float* ft, const float* attn_l, const float* at
 
 /* ---- K8: GATConv backward ------------------------------------------------------------
  * Atomics-free passes:
- *  (0) gts_gat_act_bwd_f32: g_pre = gout * act'(out) (ELU through its output; activation 0 leaves
+ *  (0) gts_gat_act_bwd_f32: g_pre = gout * act'(out) (ELU / ReLU through its output; activation 0 leaves
  *      gout as is and g_pre may be NULL) and g_bias[c] = sum_n g_pre[n,c] (optional), cols = H*D.
  *  (1) per destination row (in-CSR):  ga_k = <g_pre[v,h,:], ft[src_k,h,:]>,
  *      ge_k = a_k*(ga_k - sum_j a_j ga_j) * leaky'(el[src_k]+er[v]);  ger[v,h] = sum_k ge_k;

@@ -27,7 +27,7 @@ def test_argument_errors_do_not_need_a_gpu(hip_lib):
     assert hip_lib.gts_spmm_max_fwd_f32(None, None, None, None, None, 0, 0, 4, 4, None) == -1
     one = ctypes.c_void_p(16)
     assert hip_lib.gts_spmm_max_fwd_f32(one, one, one, one, one, 3, 0, 4, 4, None) == -3
-    assert hip_lib.gts_spmm_sum_f32(one, one, one, one, None, None, 0, -1, 4, None) == -2
+    assert hip_lib.gts_spmm_sum_f32(one, one, one, one, None, None, None, 0, -1, 4, None) == -2
     assert hip_lib.gts_project_rows_i16(one, one, one, one, 10, 10, 5, None) == -3
     assert hip_lib.gts_gat_fwd_f32(one, one, one, one, one, 0.2, None, None, 0, one, one, 4, 0, 4, None) == -2
     assert hip_lib.gts_gat_fwd_f32(one, one, one, one, one, 0.2, None, None, 7, one, one, 4, 4, 4, None) == -3

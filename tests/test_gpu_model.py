@@ -566,3 +566,27 @@ def test_row_count_invariant_batched_forward_is_bitwise_the_per_sample_forward()
     assert not torch.equal(free, sep) and torch.allclose(free, sep, rtol=1e-4, atol=1e-4)
     with torch.no_grad():                          # the pin is released on exit
         assert torch.equal(mine(g, x), free)
+
+
+@pytest.mark.parametrize("aggr", ["mean", "gcn"])
+@pytest.mark.parametrize("fin,fout", [(6, 3), (3, 6), (12, 12)])
+def test_sage_sum_layers_with_widths_that_are_not_multiples_of_four(aggr, fin, fout):
+    """Odd widths take the op-by-op route (fout % 4 != 0) or the fused node with host-side padding (fin only)."""
+    n = 200
+    src, dst = random_coo(n, 900, seed=fin + fout)
+    tg, g = ref_and_gts(src, dst, n)
+    torch.manual_seed(1)
+    ref = torch_ref.RefSAGEConv(fin, fout, aggr, activation=F.relu)
+    mine = gnn.SAGEConv(fin, fout, aggr, activation=F.relu)
+    copy_state(mine, ref)
+    mine.to(DEV)
+    x, gout = torch.randn(n, fin), torch.randn(n, fout)
+    xr = x.clone().requires_grad_(True)
+    ref(tg, xr).backward(gout)
+    xd = x.to(DEV).requires_grad_(True)
+    yd = mine(g.to(DEV), xd)
+    yd.backward(gout.to(DEV))
+    _close(yd, ref(tg, x), 1e-5, 1e-5)
+    _close(xd.grad, xr.grad, 1e-4, 1e-5)
+    for (_, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        _close(p.grad, q.grad, 1e-4, 2e-5 * max(1.0, float(q.grad.abs().max())))
