@@ -46,7 +46,12 @@ class _SagePoolLayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         h, m, arg, out, w_pool, w_self, w_neigh = ctx.saved_tensors
-        g = dense.relu_bwd(gout, out) if ctx.relu_out else gout.contiguous()
+        if not ctx.relu_out:
+            g = gout.contiguous()
+        elif out.shape[1] % 4 == 0 and out.shape[0] > 0:
+            g, _ = ops.gat_act_bwd(gout.contiguous(), out, 2, want_bias_grad=False)   # gout where out > 0, one HIP pass
+        else:
+            g = dense.relu_bwd(gout, out)
         need = ctx.needs_input_grad
         gm = dense.linear_bwd_input(g, w_neigh)
         gp = ops.spmm_max_bwd(ctx.g, gm, arg)                  # ReLU'(p) is in the winner record
