@@ -63,6 +63,12 @@ struct GemmArgs {
   const float* bias2;
   float* c2;
   int rb2, ldb2, ldc2, relu2;
+  // attention scores riding in the epilogue of the panel kernels (GATConv: el / er = <ft[n, h, :], attn_l/r[h, :]>):
+  // per output row and 64-column block the partial dot products with sc_l / sc_r [rb] go to sc_el / sc_er [ra, rb / 64]
+  const float* sc_l;
+  const float* sc_r;
+  float* sc_el;
+  float* sc_er;
 };
 
 // Phase probe of the kernel (start / operands staged / main loop done / tile stored).  The
@@ -614,6 +620,10 @@ struct PanelStage {   // one GEMM of the panel kernel: c[rows of the panel, rb] 
   float* c;
   const float* bias;
   const float* mask;
+  const float* sc_l;   // optional score vectors / partial-score outputs (see GemmArgs)
+  const float* sc_r;
+  float* sc_el;
+  float* sc_er;
 };
 
 template <int WM, int WN, int DEPTH>
@@ -701,6 +711,11 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
   const bool col_ok = col < s.rb;
   v4f bias = {0.f, 0.f, 0.f, 0.f};
   if (wide && s.bias != nullptr && col_ok) bias = *reinterpret_cast<const v4f*>(s.bias + col);
+  v4f sc_wl = {0.f, 0.f, 0.f, 0.f}, sc_wr = sc_wl;
+  if (wide && s.sc_l != nullptr && col_ok) {
+    sc_wl = *reinterpret_cast<const v4f*>(s.sc_l + col);
+    sc_wr = *reinterpret_cast<const v4f*>(s.sc_r + col);
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int row_base = m0 + wm * WTM + tm * 16;
@@ -736,6 +751,16 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
           v4f* dst = reinterpret_cast<v4f*>(s.c + static_cast<size_t>(row) * s.ldc + col);
           if (sched & 2) __builtin_nontemporal_store(val, dst);
           else *dst = val;
+        }
+        if (s.sc_l != nullptr) {   // rb is a multiple of WTN here: every lane's columns are real
+          float pl = (val[0] * sc_wl[0] + val[1] * sc_wl[1]) + (val[2] * sc_wl[2] + val[3] * sc_wl[3]);
+          float pr = (val[0] * sc_wr[0] + val[1] * sc_wr[1]) + (val[2] * sc_wr[2] + val[3] * sc_wr[3]);
+#pragma unroll
+          for (int o = 1; o < kC4; o <<= 1) pl += __shfl_xor(pl, o, kWave), pr += __shfl_xor(pr, o, kWave);
+          if (lane % kC4 == 0 && row < row_end) {
+            const size_t at = static_cast<size_t>(row) * (s.rb / WTN) + (n0 / WTN + wn);
+            s.sc_el[at] = pl, s.sc_er[at] = pr;
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -774,6 +799,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
   s0.lda[0] = p.lda[0], s0.lda[1] = p.lda[1], s0.ldb[0] = p.ldb[0], s0.ldb[1] = p.ldb[1];
   s0.kseg[0] = p.kseg[0], s0.kseg[1] = p.kseg[1];
   s0.rb = p.rb, s0.ldc = p.ldc, s0.relu = p.relu, s0.c = p.c, s0.bias = p.bias, s0.mask = p.mask;
+  s0.sc_l = p.sc_l, s0.sc_r = p.sc_r, s0.sc_el = p.sc_el, s0.sc_er = p.sc_er;
   panel_stage<WM, WN, DEPTH>(s0, lds, p.sched, m0, n0, row_end);
   Probe::mark(2);
   // With c2 set a second GEMM follows in the same launch: the rows this workgroup has just stored are
@@ -1417,6 +1443,60 @@ extern "C" int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const fl
   p.bias = bias, p.relu = relu;
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
   return launch_plain<true, true>(p, static_cast<hipStream_t>(stream));
+}
+
+namespace gts {
+namespace {
+// out[i] = sum_p in[i * parts + p] (fixed order), two arrays in one launch
+__global__ __launch_bounds__(kBlock) void sum_parts_kernel(const float* __restrict__ in_l, const float* __restrict__ in_r,
+                                                           float* __restrict__ out_l, float* __restrict__ out_r,
+                                                           int64_t n, int parts) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float sl = 0.f, sr = 0.f;
+  for (int q = 0; q < parts; ++q) sl += in_l[i * parts + q], sr += in_r[i * parts + q];
+  out_l[i] = sl, out_r[i] = sr;
+}
+}  // namespace
+}  // namespace gts
+
+extern "C" int32_t gts_gat_scores_f32(const float* ft, const float* attn_l, const float* attn_r, float* el, float* er,
+                                      int64_t n, int64_t heads, int64_t dim, void* stream);
+
+extern "C" int64_t gts_gat_fc_scores_workspace(int64_t m, int64_t heads, int64_t dim) {
+  if (m <= 0 || heads <= 0 || dim <= 0 || dim % 64 != 0) return 0;
+  return 2 * m * heads * (dim / 64) * static_cast<int64_t>(sizeof(float));
+}
+
+extern "C" int32_t gts_gat_fc_scores_f32(const float* h, const float* w_fc, const float* attn_l, const float* attn_r,
+                                         float* ft, float* el, float* er, float* workspace, int64_t workspace_bytes,
+                                         int64_t m, int64_t heads, int64_t dim, int64_t k, void* stream) {
+  using namespace gts;
+  if (!h || !w_fc || !attn_l || !attn_r || !ft || !el || !er) return GTS_ERR_NULL;
+  const int64_t n = heads * dim;
+  if (m < 0 || heads <= 0 || dim <= 0 || k <= 0 || m >= (1LL << 31) || n >= (1 << 20) || k >= (1 << 20) || !aligned4(k))
+    return GTS_ERR_SHAPE;
+  if (m == 0) return GTS_OK;
+  GemmArgs p{};
+  p.a[0] = p.a[1] = h, p.b[0] = p.b[1] = w_fc, p.lda[0] = p.ldb[0] = p.lda[1] = p.ldb[1] = static_cast<int>(k);
+  p.kseg[0] = static_cast<int>(k), p.kseg[1] = 0;
+  p.ra = static_cast<int>(m), p.rb = static_cast<int>(n), p.c = ft, p.ldc = static_cast<int>(n);
+  p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int parts = static_cast<int>(dim / 64);
+  const bool fuse = dim % 64 == 0 && pick_plain_variant<true, true>(p) == 10 &&
+                    (parts == 1 || (workspace && workspace_bytes >= gts_gat_fc_scores_workspace(m, heads, dim)));
+  if (!fuse) {   // small problems / odd head widths: the GEMM, then the scores in a pass of their own
+    const int rc = launch_plain<true, true>(p, st);
+    return rc != GTS_OK ? rc : gts_gat_scores_f32(ft, attn_l, attn_r, el, er, m, heads, dim, stream);
+  }
+  p.sc_l = attn_l, p.sc_r = attn_r;
+  p.sc_el = parts == 1 ? el : workspace, p.sc_er = parts == 1 ? er : workspace + m * heads * parts;
+  int rc = launch_plain<true, true>(p, st);
+  if (rc != GTS_OK || parts == 1) return rc;
+  const int64_t rows = m * heads;
+  sum_parts_kernel<<<static_cast<unsigned>((rows + kBlock - 1) / kBlock), kBlock, 0, st>>>(p.sc_el, p.sc_er, el, er, rows, parts);
+  return launch_status();
 }
 
 extern "C" int32_t gts_linear_fwd_chain_f32(const float* a0, const float* w0, const float* a1,

@@ -404,6 +404,7 @@ class SAGEConv(nn.Module):
 # the K5-K8 kernels).  GTS_FUSE_GAT=0 keeps the op-by-op path (same kernels for the aggregation,
 # torch for the small elementwise pieces).
 FUSE_GAT_LAYER = os.environ.get("GTS_FUSE_GAT", "1") != "0"
+FUSE_GAT_SCORES = os.environ.get("GTS_FUSE_GAT_SCORES", "1") != "0"   # el / er in the fc GEMM's epilogue (A/B switch)
 
 
 class _GATLayer(torch.autograd.Function):
@@ -415,9 +416,12 @@ class _GATLayer(torch.autograd.Function):
                 need_bwd):
         h = h.contiguous()
         n = h.shape[0]
-        ft = dense.linear_fwd(h, w_fc).view(n, heads, dim)
         al, ar = attn_l.reshape(heads, dim), attn_r.reshape(heads, dim)
-        el, er = ops.gat_scores(ft, al, ar)
+        if FUSE_GAT_SCORES and h.shape[1] % 4 == 0:
+            ft, el, er = ops.gat_fc_scores(h, w_fc, al, ar, heads, dim)     # el / er in the GEMM epilogue when tall
+        else:
+            ft = dense.linear_fwd(h, w_fc).view(n, heads, dim)
+            el, er = ops.gat_scores(ft, al, ar)
         if w_res is not None:
             res = dense.linear_fwd(h, w_res)
         elif identity_res:

@@ -244,6 +244,31 @@ def gat_scores(ft, attn_l, attn_r):
     return el, er
 
 
+def gat_fc_scores(h, w_fc, attn_l, attn_r, heads, dim):
+    """(ft [N,H,D], el [N,H], er [N,H]) = (h @ w_fc^T viewed [N,H,D], <ft, attn_l>, <ft, attn_r>): GATConv's projection
+    with the attention scores computed in the GEMM's epilogue when the operands are tall (else GEMM + gat_scores)."""
+    h, w_fc = h.contiguous(), w_fc.contiguous()
+    attn_l, attn_r = attn_l.reshape(heads, dim).contiguous(), attn_r.reshape(heads, dim).contiguous()
+    _f32(h, w_fc, attn_l, attn_r)
+    require_device(h, w_fc, attn_l, attn_r)
+    n, k = h.shape
+    if w_fc.shape != (heads * dim, k):
+        raise _lib.GtsError(f"fc weight must be [{heads * dim}, {k}], got {tuple(w_fc.shape)}")
+    if k % 4:
+        raise _lib.GtsError("gat_fc_scores needs an input width that is a multiple of 4")
+    lib = _lib.load()
+    ft = torch.empty((n, heads, dim), dtype=torch.float32, device=h.device)
+    el = torch.empty((n, heads), dtype=torch.float32, device=h.device)
+    er = torch.empty_like(el)
+    nbytes = lib.gts_gat_fc_scores_workspace(n, heads, dim)
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=h.device)
+    from . import dense
+    dense._timed("fwd", 2.0 * n * heads * dim * k, lambda: check(lib.gts_gat_fc_scores_f32(
+        ptr(h), ptr(w_fc), ptr(attn_l), ptr(attn_r), ptr(ft), ptr(el), ptr(er), ptr(ws), ws.numel() * 4, n, heads, dim, k,
+        current_stream()), "gts_gat_fc_scores_f32"))
+    return ft, el, er
+
+
 def _reduce_ws(n, cols, device):
     nbytes = _lib.load().gts_gat_reduce_workspace(n, cols)
     return torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=device)

@@ -341,3 +341,26 @@ def test_device_csr_is_owned_by_the_device_views_not_by_the_cached_host_graph():
     gc.collect()
     assert alive() is None and host.device.type == "cpu"
     assert host.to(DEV).dev().indptr.numel() == 201             # and it is rebuilt on demand
+
+
+@pytest.mark.parametrize("n,heads,dim,k", [(60000, 4, 256, 1024), (60000, 4, 64, 4), (49999, 2, 128, 132), (300, 4, 256, 64),
+                                          (60000, 3, 48, 64)])
+def test_gat_projection_with_scores_in_the_gemm_epilogue(n, heads, dim, k):
+    """gts_gat_fc_scores_f32: ft bitwise the plain GEMM's; el / er within fp32 rounding of the separate pass
+    (gat_scores) and of fp64 — fused epilogue at the tall shapes with dim % 64 == 0, GEMM + gat_scores otherwise."""
+    from gts import dense
+
+    gen = torch.Generator().manual_seed(n + dim)
+    h = torch.randn(n, k, generator=gen).to(DEV)
+    w = (torch.randn(heads * dim, k, generator=gen) * 0.1).to(DEV)
+    al, ar = torch.randn(heads, dim, generator=gen).to(DEV), torch.randn(heads, dim, generator=gen).to(DEV)
+    ft, el, er = ops.gat_fc_scores(h, w, al, ar, heads, dim)
+    want_ft = dense.linear_fwd(h, w).view(n, heads, dim)
+    assert torch.equal(ft, want_ft)
+    el2, er2 = ops.gat_scores(want_ft, al, ar)
+    ref_l = (want_ft.double() * al.double()).sum(-1)
+    ref_r = (want_ft.double() * ar.double()).sum(-1)
+    bound = (want_ft.double().abs() * al.double().abs()).sum(-1)
+    assert torch.all((el.double() - ref_l).abs() <= 2e-6 * bound + 1e-30)
+    assert torch.all((er.double() - ref_r).abs() <= 2e-6 * (want_ft.double().abs() * ar.double().abs()).sum(-1) + 1e-30)
+    assert torch.allclose(el, el2, rtol=1e-5, atol=1e-5) and torch.allclose(er, er2, rtol=1e-5, atol=1e-5)
