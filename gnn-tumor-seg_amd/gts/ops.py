@@ -252,8 +252,10 @@ def gat_fc_scores(h, w_fc, attn_l, attn_r, heads, dim):
     _f32(h, w_fc, attn_l, attn_r)
     require_device(h, w_fc, attn_l, attn_r)
     n, k = h.shape
-    if w_fc.shape != (heads * dim, k):
-        raise _lib.GtsError(f"fc weight must be [{heads * dim}, {k}], got {tuple(w_fc.shape)}")
+    if w_fc.dim() != 2 or w_fc.shape[1] != k:
+        raise _lib.GtsError(f"shapes do not match: inner dims of h @ fc.weight^T ({k} vs {tuple(w_fc.shape)[-1]})")
+    if w_fc.shape[0] != heads * dim:
+        raise _lib.GtsError(f"shapes do not match: fc.weight rows ({w_fc.shape[0]}) vs heads * out_feats ({heads * dim})")
     if k % 4:
         raise _lib.GtsError("gat_fc_scores needs an input width that is a multiple of 4")
     lib = _lib.load()
