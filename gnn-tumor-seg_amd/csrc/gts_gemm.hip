@@ -69,6 +69,10 @@ struct GemmArgs {
   const float* sc_r;
   float* sc_el;
   float* sc_er;
+  // ReLU masks as bits (layout: gts_relu_bits_bytes in gts_hip.h).  bits_out: c > 0 is recorded while c is stored;
+  // bits_in: the same mask as `mask`, read by the kernels that can (the others read the floats of `mask`)
+  unsigned long long* bits_out;
+  const unsigned long long* bits_in;
 };
 
 // Phase probe of the kernel (start / operands staged / main loop done / tile stored).  The
@@ -616,7 +620,7 @@ struct PanelStage {   // one GEMM of the panel kernel: c[rows of the panel, rb] 
   const float* a[2];
   const float* b[2];
   int lda[2], ldb[2], kseg[2];
-  int rb, ldc, relu;
+  int ra, rb, ldc, relu;
   float* c;
   const float* bias;
   const float* mask;
@@ -624,6 +628,8 @@ struct PanelStage {   // one GEMM of the panel kernel: c[rows of the panel, rb] 
   const float* sc_r;
   float* sc_el;
   float* sc_er;
+  unsigned long long* bits_out;        // optional: sign bits of c (see GemmArgs)
+  const unsigned long long* bits_in;   // optional: `mask` as bits
 };
 
 template <int WM, int WN, int DEPTH>
@@ -631,7 +637,7 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
   constexpr int WTM = kR240 / WM, WTN = kC240 / WN, TM = WTM / 16, TN = WTN / 16;
   constexpr int R = DEPTH + 1;                     // register sets of fragments
   constexpr int kLd = WTN + 4, kStage = 16 * kLd;  // per-wave epilogue patch [16][WTN + 4]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
   const int wm = wave / WN, wn = wave % WN;
   const int i16 = lane & 15, q = lane >> 4;
 
@@ -716,12 +722,21 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
     sc_wl = *reinterpret_cast<const v4f*>(s.sc_l + col);
     sc_wr = *reinterpret_cast<const v4f*>(s.sc_r + col);
   }
+  // ReLU masks as bits (GemmArgs::bits_out / bits_in): this wave's TM * 4 row groups of its 64-column block are
+  // TM * 16 consecutive words of the [column block][row group][4] layout
+  constexpr int kBitWords = TM * 16;
+  const bool bits_here = WTN == 64 && wide && n0 + wn * WTN < s.rb;
+  const bool bit_mask = bits_here && s.bits_in != nullptr && s.mask != nullptr;
+  const bool bits_wanted = bits_here && s.bits_out != nullptr;
+  const size_t bits_at = (static_cast<size_t>((n0 + wn * WTN) >> 6) * ((s.ra + 3) >> 2) + ((m0 + wm * WTM) >> 2)) * 4;
+  unsigned long long* bit_words = reinterpret_cast<unsigned long long*>(lds + WM * WN * kStage) + wave * kBitWords;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int row_base = m0 + wm * WTM + tm * 16;
     if (wide) {
       v4f mk[16 / kRowsPerIt];
-      if (s.mask != nullptr) {
+      const bool float_mask = s.mask != nullptr && !bit_mask;
+      if (float_mask) {
 #pragma unroll
         for (int it = 0; it < 16 / kRowsPerIt; ++it) {
           const int row = row_base + it * kRowsPerIt + rsub;
@@ -739,18 +754,30 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
       for (int it = 0; it < 16 / kRowsPerIt; ++it) {
         const int lrow = it * kRowsPerIt + rsub, row = row_base + lrow;
         v4f val = *reinterpret_cast<const v4f*>(stage + lrow * kLd + c4) + bias;
+        // four rows x 64 columns per pass: their four mask words (bit = lane) sit at one wave-uniform
+        // address — scalar loads, which do not queue behind this wave's stores as vector loads do
+        if (bit_mask && row_base + it * kRowsPerIt < row_end) {
+          const unsigned long long* words = s.bits_in + bits_at + (tm * (16 / kRowsPerIt) + it) * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) val[e] = (words[e] >> lane) & 1ull ? val[e] : 0.f;
+        }
         if (row < row_end && col_ok) {
           if (s.relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
           }
-          if (s.mask != nullptr) {
+          if (float_mask) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) val[e] = mk[it][e] > 0.f ? val[e] : 0.f;
           }
           v4f* dst = reinterpret_cast<v4f*>(s.c + static_cast<size_t>(row) * s.ldc + col);
           if (sched & 2) __builtin_nontemporal_store(val, dst);
           else *dst = val;
+        }
+        if (bits_wanted) {   // one wave-wide comparison per element slot = one word; collected in LDS, stored once
+          const unsigned long long w0 = __ballot(val[0] > 0.f), w1 = __ballot(val[1] > 0.f);
+          const unsigned long long w2 = __ballot(val[2] > 0.f), w3 = __ballot(val[3] > 0.f);
+          if (lane < 4) bit_words[(tm * (16 / kRowsPerIt) + it) * 4 + lane] = lane == 0 ? w0 : lane == 1 ? w1 : lane == 2 ? w2 : w3;
         }
         if (s.sc_l != nullptr) {   // rb is a multiple of WTN here: every lane's columns are real
           float pl = (val[0] * sc_wl[0] + val[1] * sc_wl[1]) + (val[2] * sc_wl[2] + val[3] * sc_wl[3]);
@@ -783,13 +810,22 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
       }
     }
   }
+  if (bits_wanted) {
+    __builtin_amdgcn_wave_barrier();
+    const int valid = min(kBitWords, ((row_end - (m0 + wm * WTM) + 3) >> 2) * 4);   // words of rows that exist
+#pragma unroll
+    for (int base = 0; base < kBitWords; base += 64)
+      if (base + lane < valid) s.bits_out[bits_at + base + lane] = bit_words[base + lane];
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 template <int WM, int WN, int DEPTH, class Probe = NoProbe>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_kernel(const GemmArgs p) {
   constexpr int WTN = kC240 / WN;
   static_assert((kR240 / WM) % 16 == 0 && WTN % 16 == 0 && WTN % 4 == 0 && (WM * WN) % 4 == 0, "wave tiles are whole 16x16 tiles");
-  __shared__ float lds[WM * WN * 16 * (WTN + 4)];   // epilogue patches only
+  // epilogue patches [16][WTN + 4] per wave, then the waves' mask words (kR240 / WM / 16 * 16 of 8 bytes each)
+  __shared__ __attribute__((aligned(16))) float lds[WM * WN * 16 * (WTN + 4) + WM * WN * (kR240 / WM) * 2];
   const int m0 = blockIdx.x * kR240, n0 = blockIdx.y * kC240;
   const int row_end = min(p.ra, m0 + kR240);
   Probe::mark(0);
@@ -798,8 +834,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
   s0.a[0] = p.a[0], s0.a[1] = p.a[1], s0.b[0] = p.b[0], s0.b[1] = p.b[1];
   s0.lda[0] = p.lda[0], s0.lda[1] = p.lda[1], s0.ldb[0] = p.ldb[0], s0.ldb[1] = p.ldb[1];
   s0.kseg[0] = p.kseg[0], s0.kseg[1] = p.kseg[1];
-  s0.rb = p.rb, s0.ldc = p.ldc, s0.relu = p.relu, s0.c = p.c, s0.bias = p.bias, s0.mask = p.mask;
+  s0.ra = p.ra, s0.rb = p.rb, s0.ldc = p.ldc, s0.relu = p.relu, s0.c = p.c, s0.bias = p.bias, s0.mask = p.mask;
   s0.sc_l = p.sc_l, s0.sc_r = p.sc_r, s0.sc_el = p.sc_el, s0.sc_er = p.sc_er;
+  s0.bits_out = p.bits_out, s0.bits_in = p.bits_in;
   panel_stage<WM, WN, DEPTH>(s0, lds, p.sched, m0, n0, row_end);
   Probe::mark(2);
   // With c2 set a second GEMM follows in the same launch: the rows this workgroup has just stored are
@@ -814,7 +851,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
     s1.a[0] = p.c, s1.a[1] = p.c, s1.b[0] = p.b2, s1.b[1] = p.b2;
     s1.lda[0] = s1.lda[1] = p.ldc, s1.ldb[0] = s1.ldb[1] = p.ldb2;
     s1.kseg[0] = p.rb, s1.kseg[1] = 0;
-    s1.rb = p.rb2, s1.ldc = p.ldc2, s1.relu = p.relu2, s1.c = p.c2, s1.bias = p.bias2, s1.mask = nullptr;
+    s1.ra = p.ra, s1.rb = p.rb2, s1.ldc = p.ldc2, s1.relu = p.relu2, s1.c = p.c2, s1.bias = p.bias2, s1.mask = nullptr;
     panel_stage<WM, WN, DEPTH>(s1, lds, p.sched, m0, 0, row_end);
   }
   Probe::mark(3);
@@ -1302,6 +1339,38 @@ int pick_plain_variant(const GemmArgs& p) {
   return variant;
 }
 
+// bits[((col / 64) * ceil(rows / 4) + row / 4) * 4 + e], bit 16 (row % 4) + (col % 64) / 4  <=>  c[row][64 (col / 64) + 4 ((col % 64) / 4) + e] > 0:
+// the layout the panel kernels write from their epilogue, here for the outputs of the other tile variants
+__global__ __launch_bounds__(256) void relu_bits_kernel(const float* __restrict__ c, unsigned long long* __restrict__ bits,
+                                                        int rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int blocks = cols >> 6;
+  const long long id = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const long long group = id / blocks;
+  const int cb = static_cast<int>(id % blocks);
+  if (group * 4 >= rows) return;
+  const long long row = group * 4 + (lane >> 4);
+  v4f v = {0.f, 0.f, 0.f, 0.f};
+  if (row < rows) v = *reinterpret_cast<const v4f*>(c + row * cols + 64 * cb + 4 * (lane & 15));
+  const unsigned long long w0 = __ballot(v[0] > 0.f), w1 = __ballot(v[1] > 0.f);
+  const unsigned long long w2 = __ballot(v[2] > 0.f), w3 = __ballot(v[3] > 0.f);
+  const long long groups = (rows + 3) >> 2;
+  if (lane < 4) bits[(cb * groups + group) * 4 + lane] = lane == 0 ? w0 : lane == 1 ? w1 : lane == 2 ? w2 : w3;
+}
+
+template <bool AKC, bool BKC>
+int launch_plain_tiles(const GemmArgs& p, int variant, hipStream_t st) {
+  if (p.rb <= 64) return launch_tiles<128, 64, 2, 2, AKC, BKC>(p, 1, 1, st);
+  if (p.rb <= 128) return launch_tiles<128, 128, 2, 2, AKC, BKC>(p, 1, 1, st);
+  switch (variant) {
+    // the variants that survived the sweeps in profiles/r01_tune_gemm.log (numbers kept from there)
+    case 3: return launch_tiles<64, 256, 2, 4, AKC, BKC>(p, 1, 1, st);
+    case 5: return launch_tiles<256, 128, 4, 2, AKC, BKC>(p, 1, 1, st);
+    case 8: return launch_tiles<256, 256, 4, 4, AKC, BKC, true>(p, 1, 1, st);
+    default: return launch_tiles<128, 256, 2, 4, AKC, BKC>(p, 1, 1, st);   // 1
+  }
+}
+
 template <bool AKC, bool BKC>
 int launch_plain(const GemmArgs& p, hipStream_t st) {
   const int variant = pick_plain_variant<AKC, BKC>(p);
@@ -1320,20 +1389,19 @@ int launch_plain(const GemmArgs& p, hipStream_t st) {
       next.tiles_per_split = (p.rb + kBK - 1) / kBK;
       return launch_plain<true, true>(next, st);
     }
-    if (variant == 9) return launch_rows240(p, st);
+    // the panel kernels keep the mask bits themselves (written / read in their epilogue)
     if (variant == 10) return launch_panel_direct<3, 4, 1>(p, st);
     if (variant == 11) return launch_panel_direct<1, 4, 1>(p, st);
     if (variant == 12) return launch_panel_direct<1, 4, 2>(p, st);
   }
-  if (p.rb <= 64) return launch_tiles<128, 64, 2, 2, AKC, BKC>(p, 1, 1, st);
-  if (p.rb <= 128) return launch_tiles<128, 128, 2, 2, AKC, BKC>(p, 1, 1, st);
-  switch (variant) {
-    // the variants that survived the sweeps in profiles/r01_tune_gemm.log (numbers kept from there)
-    case 3: return launch_tiles<64, 256, 2, 4, AKC, BKC>(p, 1, 1, st);
-    case 5: return launch_tiles<256, 128, 4, 2, AKC, BKC>(p, 1, 1, st);
-    case 8: return launch_tiles<256, 256, 4, 4, AKC, BKC, true>(p, 1, 1, st);
-    default: return launch_tiles<128, 256, 2, 4, AKC, BKC>(p, 1, 1, st);   // 1
-  }
+  // every other tile: the float mask is read as before, and the bits of the output come from a pass of their own
+  int rc = GTS_OK;
+  if (AKC && BKC && variant == 9) rc = launch_rows240(p, st);
+  else rc = launch_plain_tiles<AKC, BKC>(p, variant, st);
+  if (rc != GTS_OK || p.bits_out == nullptr) return rc;
+  const long long words = static_cast<long long>((p.ra + 3) / 4) * (p.rb >> 6);
+  relu_bits_kernel<<<static_cast<unsigned>((words + 3) / 4), 256, 0, st>>>(p.c, p.bits_out, p.ra, p.rb);
+  return launch_status();
 }
 
 // Split-reduction plan of a weight-gradient launch: tile variant, its edge lengths, and how many
@@ -1427,11 +1495,12 @@ extern "C" int32_t gts_set_option(int32_t option, int32_t value) {
 extern "C" int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const float* a1,
                                       const float* w1, const float* bias, float* out, int64_t m,
                                       int64_t n, int64_t k0, int64_t k1, int32_t relu,
-                                      void* stream) {
+                                      uint64_t* relu_bits, void* stream) {
   using namespace gts;
   if (!a0 || !w0 || !out || ((a1 == nullptr) != (w1 == nullptr))) return GTS_ERR_NULL;
   if (m < 0 || n <= 0 || k0 <= 0 || k1 < 0 || m >= (1LL << 31) || n >= (1 << 20) ||
-      k0 >= (1 << 20) || k1 >= (1 << 20) || !aligned4(k0) || !aligned4(k1) || (a1 && k1 == 0))
+      k0 >= (1 << 20) || k1 >= (1 << 20) || !aligned4(k0) || !aligned4(k1) || (a1 && k1 == 0) ||
+      (relu_bits && n % 64 != 0))
     return GTS_ERR_SHAPE;
   if (m == 0) return GTS_OK;
   GemmArgs p{};
@@ -1441,8 +1510,14 @@ extern "C" int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const fl
   p.lda[1] = p.ldb[1] = static_cast<int>(k1), p.kseg[1] = a1 ? static_cast<int>(k1) : 0;
   p.ra = static_cast<int>(m), p.rb = static_cast<int>(n), p.c = out, p.ldc = static_cast<int>(n);
   p.bias = bias, p.relu = relu;
+  p.bits_out = reinterpret_cast<unsigned long long*>(relu_bits);
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
   return launch_plain<true, true>(p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t gts_relu_bits_bytes(int64_t m, int64_t n) {
+  if (m < 0 || n <= 0 || n % 64 != 0) return 0;
+  return (m + 3) / 4 * (n / 64) * 4 * static_cast<int64_t>(sizeof(uint64_t));
 }
 
 namespace gts {
@@ -1503,11 +1578,12 @@ extern "C" int32_t gts_linear_fwd_chain_f32(const float* a0, const float* w0, co
                                             const float* w1, const float* bias, float* out,
                                             const float* w2, const float* bias2, float* out2, int64_t m,
                                             int64_t n, int64_t k0, int64_t k1, int32_t relu, int64_t n2,
-                                            int32_t relu2, void* stream) {
+                                            int32_t relu2, uint64_t* relu_bits, void* stream) {
   using namespace gts;
   if (!a0 || !w0 || !out || !w2 || !out2 || ((a1 == nullptr) != (w1 == nullptr))) return GTS_ERR_NULL;
   if (m < 0 || n <= 0 || n2 <= 0 || k0 <= 0 || k1 < 0 || m >= (1LL << 31) || n >= (1 << 20) || n2 >= (1 << 20) ||
-      k0 >= (1 << 20) || k1 >= (1 << 20) || !aligned4(k0) || !aligned4(k1) || !aligned4(n) || (a1 && k1 == 0))
+      k0 >= (1 << 20) || k1 >= (1 << 20) || !aligned4(k0) || !aligned4(k1) || !aligned4(n) || (a1 && k1 == 0) ||
+      (relu_bits && n % 64 != 0))
     return GTS_ERR_SHAPE;
   if (m == 0) return GTS_OK;
   GemmArgs p{};
@@ -1517,6 +1593,7 @@ extern "C" int32_t gts_linear_fwd_chain_f32(const float* a0, const float* w0, co
   p.lda[1] = p.ldb[1] = static_cast<int>(k1), p.kseg[1] = a1 ? static_cast<int>(k1) : 0;
   p.ra = static_cast<int>(m), p.rb = static_cast<int>(n), p.c = out, p.ldc = static_cast<int>(n);
   p.bias = bias, p.relu = relu;
+  p.bits_out = reinterpret_cast<unsigned long long*>(relu_bits);
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
   p.b2 = w2, p.bias2 = bias2, p.c2 = out2, p.rb2 = static_cast<int>(n2), p.ldb2 = static_cast<int>(n);
   p.ldc2 = static_cast<int>(n2), p.relu2 = relu2;
@@ -1524,13 +1601,16 @@ extern "C" int32_t gts_linear_fwd_chain_f32(const float* a0, const float* w0, co
 }
 
 extern "C" int32_t gts_linear_bwd_input_chain_t_f32(const float* g0, const float* w0t, const float* g1,
-                                                    const float* w1t, const float* relu_mask, float* gin,
+                                                    const float* w1t, const float* relu_mask,
+                                                    const uint64_t* relu_bits, float* gin,
                                                     const float* w2t, float* gin2, int64_t m, int64_t k,
                                                     int64_t n0, int64_t n1, int64_t k2, void* stream) {
   using namespace gts;
-  if (!g0 || !w0t || !gin || !w2t || !gin2 || ((g1 == nullptr) != (w1t == nullptr))) return GTS_ERR_NULL;
+  if (!g0 || !w0t || !gin || !w2t || !gin2 || ((g1 == nullptr) != (w1t == nullptr)) || (relu_bits && !relu_mask))
+    return GTS_ERR_NULL;
   if (m < 0 || k <= 0 || k2 <= 0 || n0 <= 0 || n1 < 0 || m >= (1LL << 31) || k >= (1 << 20) || k2 >= (1 << 20) ||
-      n0 >= (1 << 20) || n1 >= (1 << 20) || !aligned4(k) || !aligned4(n0) || !aligned4(n1) || (g1 && n1 == 0))
+      n0 >= (1 << 20) || n1 >= (1 << 20) || !aligned4(k) || !aligned4(n0) || !aligned4(n1) || (g1 && n1 == 0) ||
+      (relu_bits && k % 64 != 0))
     return GTS_ERR_SHAPE;
   if (m == 0) return GTS_OK;
   GemmArgs p{};
@@ -1538,7 +1618,7 @@ extern "C" int32_t gts_linear_bwd_input_chain_t_f32(const float* g0, const float
   p.a[1] = g1 ? g1 : g0, p.b[1] = w1t ? w1t : w0t;
   p.lda[1] = p.ldb[1] = static_cast<int>(n1), p.kseg[1] = g1 ? static_cast<int>(n1) : 0;
   p.ra = static_cast<int>(m), p.rb = static_cast<int>(k), p.c = gin, p.ldc = static_cast<int>(k);
-  p.mask = relu_mask;
+  p.mask = relu_mask, p.bits_in = reinterpret_cast<const unsigned long long*>(relu_bits);
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
   p.b2 = w2t, p.bias2 = nullptr, p.c2 = gin2, p.rb2 = static_cast<int>(k2), p.ldb2 = static_cast<int>(k);
   p.ldc2 = static_cast<int>(k2), p.relu2 = 0;
@@ -1570,14 +1650,15 @@ extern "C" int32_t gts_linear_bwd_input_f32(const float* g0, const float* w0, co
 }
 
 extern "C" int32_t gts_linear_bwd_input_t_f32(const float* g0, const float* w0t, const float* g1,
-                                              const float* w1t, const float* relu_mask, float* gin,
+                                              const float* w1t, const float* relu_mask,
+                                              const uint64_t* relu_bits, float* gin,
                                               int64_t m, int64_t k, int64_t n0, int64_t n1,
                                               void* stream) {
   using namespace gts;
-  if (!g0 || !w0t || !gin || ((g1 == nullptr) != (w1t == nullptr))) return GTS_ERR_NULL;
+  if (!g0 || !w0t || !gin || ((g1 == nullptr) != (w1t == nullptr)) || (relu_bits && !relu_mask)) return GTS_ERR_NULL;
   if (m < 0 || k <= 0 || n0 <= 0 || n1 < 0 || m >= (1LL << 31) || k >= (1 << 20) ||
       n0 >= (1 << 20) || n1 >= (1 << 20) || !aligned4(k) || !aligned4(n0) || !aligned4(n1) ||
-      (g1 && n1 == 0))
+      (g1 && n1 == 0) || (relu_bits && k % 64 != 0))
     return GTS_ERR_SHAPE;
   if (m == 0) return GTS_OK;
   GemmArgs p{};
@@ -1586,7 +1667,7 @@ extern "C" int32_t gts_linear_bwd_input_t_f32(const float* g0, const float* w0t,
   p.a[1] = g1 ? g1 : g0, p.b[1] = w1t ? w1t : w0t;
   p.lda[1] = p.ldb[1] = static_cast<int>(n1), p.kseg[1] = g1 ? static_cast<int>(n1) : 0;
   p.ra = static_cast<int>(m), p.rb = static_cast<int>(k), p.c = gin, p.ldc = static_cast<int>(k);
-  p.mask = relu_mask;
+  p.mask = relu_mask, p.bits_in = reinterpret_cast<const unsigned long long*>(relu_bits);
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
   return launch_plain<true, true>(p, static_cast<hipStream_t>(stream));
 }

@@ -10,7 +10,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgts_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "gts_hip.h")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -40,14 +40,15 @@ SIGNATURES = {
     "gts_adamw_f32": [_p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _i64, _p],
     "gts_label_confusion_workspace": [_i64],
     "gts_label_confusion_i16": [_p, _p, _p, _p, _i64, _i64, _p],
-    "gts_linear_fwd_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p],
+    "gts_linear_fwd_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p, _p],
+    "gts_relu_bits_bytes": [_i64, _i64],
     "gts_linear_bwd_input_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
-    "gts_linear_bwd_input_t_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
+    "gts_linear_bwd_input_t_f32": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "gts_transpose_batch_f32": [_p, _p, _i32, _i64, _i64, _p],
     "gts_gat_fc_scores_workspace": [_i64, _i64, _i64],
     "gts_gat_fc_scores_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
-    "gts_linear_fwd_chain_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _i64, _i32, _p],
-    "gts_linear_bwd_input_chain_t_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "gts_linear_fwd_chain_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _i64, _i32, _p, _p],
+    "gts_linear_bwd_input_chain_t_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "gts_linear_bwd_weight_workspace": [_i64, _i64, _i64, _i32],
     "gts_linear_bwd_weight_f32": [_p, _p, _p, _p, _i32, _p, _i64, _i64, _i64, _i64, _p],
     "gts_set_option": [_i32, _i32],
@@ -56,7 +57,8 @@ SIGNATURES = {
 }
 _RESTYPE = {"gts_error_string": ctypes.c_char_p, "gts_linear_bwd_weight_workspace": _i64,
             "gts_weighted_ce_workspace": _i64, "gts_gat_reduce_workspace": _i64,
-            "gts_label_confusion_workspace": _i64, "gts_gat_fc_scores_workspace": _i64}
+            "gts_label_confusion_workspace": _i64, "gts_gat_fc_scores_workspace": _i64,
+            "gts_relu_bits_bytes": _i64}
 
 _lib = None
 

@@ -86,8 +86,34 @@ def _chk(*tensors):
     return require_device(*tensors)
 
 
-def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False):
-    """out = act(a0 @ w0^T [+ a1 @ w1^T] + bias).  a [M,K], w [N,K] (torch Linear layout)."""
+def relu_bits_empty(m, n, device):
+    """Buffer for the sign bits of an [m, n] activation (n % 64 == 0): what `relu_bits=` of the forward calls
+    fills and `relu_bits=` of the transposed input-gradient calls reads (layout: include/gts_hip.h)."""
+    nbytes = _lib.load().gts_relu_bits_bytes(m, n)
+    if nbytes == 0 and m > 0:
+        raise _lib.GtsError(f"relu bits need a width that is a multiple of 64, got {n}")
+    return torch.empty(nbytes // 8, dtype=torch.int64, device=device)
+
+
+def _chk_bits(bits, m, n, what):
+    if bits is None:
+        return
+    if bits.dtype != torch.int64 or not bits.is_contiguous() or bits.numel() * 8 != _lib.load().gts_relu_bits_bytes(m, n):
+        raise _lib.GtsError(f"shapes do not match: {what} must come from relu_bits_empty({m}, {n})")
+
+
+def unpack_relu_bits(bits, m, n):
+    """[m, n] bool tensor from the bit layout (tests / debugging; a few torch ops, not a hot path)."""
+    words = bits.view(n // 64, (m + 3) // 4, 4)                            # [column block, row group, e]
+    lanes = torch.arange(64, device=bits.device, dtype=torch.int64)
+    on = ((words.unsqueeze(-1) >> lanes) & 1).bool()                       # [..., e, lane = 16 * (row % 4) + j]
+    on = on.view(n // 64, -1, 4, 4, 16).permute(1, 3, 0, 4, 2)             # [group, row % 4, block, j, e]
+    return on.reshape(-1, n)[:m]
+
+
+def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False, relu_bits=None):
+    """out = act(a0 @ w0^T [+ a1 @ w1^T] + bias).  a [M,K], w [N,K] (torch Linear layout).
+    relu_bits (from relu_bits_empty): also filled with out > 0, one bit per element."""
     _same(_mat(a0, "a0").shape[1], _mat(w0, "w0").shape[1], "inner dims of a0 @ w0^T")
     if (a1 is None) != (w1 is None):
         raise _lib.GtsError("a1 and w1 go together")
@@ -102,24 +128,26 @@ def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False):
         a1, w1 = _pad4_cols(a1), _pad4_cols(w1)
     dev = _chk(a0, w0, a1, w1, bias)
     m, n = a0.shape[0], w0.shape[0]
+    _chk_bits(relu_bits, m, n, "relu_bits")
     out = torch.empty((m, n), dtype=torch.float32, device=dev)
     k0, k1 = a0.shape[1], a1.shape[1] if a1 is not None else 0
     bias = bias.contiguous() if bias is not None else None
 
     def launch():
         check(_lib.load().gts_linear_fwd_f32(ptr(a0), ptr(w0), ptr(a1), ptr(w1), ptr(bias), ptr(out),
-                                             m, n, k0, k1, 1 if relu else 0, current_stream()),
+                                             m, n, k0, k1, 1 if relu else 0, ptr(relu_bits), current_stream()),
               "gts_linear_fwd_f32")
 
     _timed("fwd", 2.0 * m * n * (k0 + k1), launch)
     return out
 
 
-def linear_fwd_chain(a0, w0, a1, w1, bias, relu, w2, bias2, relu2):
+def linear_fwd_chain(a0, w0, a1, w1, bias, relu, w2, bias2, relu2, relu_bits=None):
     """(out, out2) with out = act(a0 @ w0^T [+ a1 @ w1^T] + bias) and out2 = act2(out @ w2^T + bias2): the two
     GEMMs of consecutive layers in ONE launch when the operands are tall and at most 256 wide (the workgroup
     that has produced a row panel of `out` multiplies it on), otherwise two launches — same values either way.
-    All widths must be multiples of 4 (no padding here: callers fall back to two linear_fwd calls)."""
+    All widths must be multiples of 4 (no padding here: callers fall back to two linear_fwd calls).
+    relu_bits: filled with out > 0 (as in linear_fwd)."""
     _same(_mat(a0, "a0").shape[1], _mat(w0, "w0").shape[1], "inner dims of a0 @ w0^T")
     if (a1 is None) != (w1 is None):
         raise _lib.GtsError("a1 and w1 go together")
@@ -137,18 +165,21 @@ def linear_fwd_chain(a0, w0, a1, w1, bias, relu, w2, bias2, relu2):
     if n % 4 or k0 % 4 or k1 % 4:
         raise _lib.GtsError("linear_fwd_chain needs widths that are multiples of 4")
     dev = _chk(a0, w0, a1, w1, bias, w2, bias2)
+    _chk_bits(relu_bits, m, n, "relu_bits")
     out = torch.empty((m, n), dtype=torch.float32, device=dev)
     out2 = torch.empty((m, n2), dtype=torch.float32, device=dev)
     _timed("fwd", 2.0 * m * n * (k0 + k1) + 2.0 * m * n2 * n, lambda: check(
         _lib.load().gts_linear_fwd_chain_f32(ptr(a0), ptr(w0), ptr(a1), ptr(w1), ptr(bias), ptr(out), ptr(w2),
                                              ptr(bias2), ptr(out2), m, n, k0, k1, 1 if relu else 0, n2,
-                                             1 if relu2 else 0, current_stream()), "gts_linear_fwd_chain_f32"))
+                                             1 if relu2 else 0, ptr(relu_bits), current_stream()),
+        "gts_linear_fwd_chain_f32"))
     return out, out2
 
 
-def linear_bwd_input_chain_t(g0, w0t, g1, w1t, relu_mask, w2t):
+def linear_bwd_input_chain_t(g0, w0t, g1, w1t, relu_mask, w2t, relu_bits=None):
     """(gin, gin2) with gin = (g0 @ w0 [+ g1 @ w1]) (zeroed where relu_mask <= 0) and gin2 = gin @ w2, from
-    TRANSPOSED weights (w0t [K,N0], w1t [K,N1], w2t [K2,K]); one launch under the conditions of linear_fwd_chain."""
+    TRANSPOSED weights (w0t [K,N0], w1t [K,N1], w2t [K2,K]); one launch under the conditions of linear_fwd_chain.
+    relu_bits: relu_mask > 0 as bits (from the forward call that made relu_mask) — read instead of its floats."""
     _same(_mat(g0, "g0").shape[1], _mat(w0t, "w0t").shape[1], "inner dims of g0 @ w0t^T")
     if (g1 is None) != (w1t is None):
         raise _lib.GtsError("g1 and w1t go together")
@@ -164,11 +195,14 @@ def linear_bwd_input_chain_t(g0, w0t, g1, w1t, relu_mask, w2t):
     if k % 4 or n0 % 4 or n1 % 4:
         raise _lib.GtsError("linear_bwd_input_chain_t needs widths that are multiples of 4")
     dev = _chk(g0, w0t, g1, w1t, relu_mask, w2t)
+    _chk_bits(relu_bits if relu_mask is not None else None, m, k, "relu_bits")
+    relu_bits = relu_bits if relu_mask is not None else None
     gin = torch.empty((m, k), dtype=torch.float32, device=dev)
     gin2 = torch.empty((m, k2), dtype=torch.float32, device=dev)
     _timed("igrad", 2.0 * m * k * (n0 + n1) + 2.0 * m * k2 * k, lambda: check(
-        _lib.load().gts_linear_bwd_input_chain_t_f32(ptr(g0), ptr(w0t), ptr(g1), ptr(w1t), ptr(relu_mask), ptr(gin),
-                                                     ptr(w2t), ptr(gin2), m, k, n0, n1, k2, current_stream()),
+        _lib.load().gts_linear_bwd_input_chain_t_f32(ptr(g0), ptr(w0t), ptr(g1), ptr(w1t), ptr(relu_mask),
+                                                     ptr(relu_bits), ptr(gin), ptr(w2t), ptr(gin2), m, k, n0, n1, k2,
+                                                     current_stream()),
         "gts_linear_bwd_input_chain_t_f32"))
     return gin, gin2
 
@@ -219,9 +253,10 @@ def transpose_batch(mats):
     return list(out.unbind(0))
 
 
-def linear_bwd_input_t(g0, w0t, g1=None, w1t=None, relu_mask=None):
+def linear_bwd_input_t(g0, w0t, g1=None, w1t=None, relu_mask=None, relu_bits=None):
     """linear_bwd_input from TRANSPOSED weights (w0t [K,N0] = w0.t(), from transpose_batch): the
-    GEMM then runs in the forward kernel's form.  Same values, bit for bit.  All widths % 4 == 0."""
+    GEMM then runs in the forward kernel's form.  Same values, bit for bit.  All widths % 4 == 0.
+    relu_bits: relu_mask > 0 as bits (see linear_fwd) — read instead of the floats where the kernel can."""
     _same(_mat(g0, "g0").shape[1], _mat(w0t, "w0t").shape[1], "inner dims of g0 @ w0t^T")
     if (g1 is None) != (w1t is None):
         raise _lib.GtsError("g1 and w1t go together")
@@ -236,10 +271,12 @@ def linear_bwd_input_t(g0, w0t, g1=None, w1t=None, relu_mask=None):
     if k % 4 or n0 % 4 or n1 % 4:
         raise _lib.GtsError("linear_bwd_input_t needs widths that are multiples of 4 (use linear_bwd_input)")
     dev = _chk(g0, w0t, g1, w1t, relu_mask)
+    relu_bits = relu_bits if relu_mask is not None else None
+    _chk_bits(relu_bits, m, k, "relu_bits")
     gin = torch.empty((m, k), dtype=torch.float32, device=dev)
     _timed("igrad", 2.0 * m * k * (n0 + n1), lambda: check(
-        _lib.load().gts_linear_bwd_input_t_f32(ptr(g0), ptr(w0t), ptr(g1), ptr(w1t), ptr(relu_mask), ptr(gin),
-                                               m, k, n0, n1, current_stream()), "gts_linear_bwd_input_t_f32"))
+        _lib.load().gts_linear_bwd_input_t_f32(ptr(g0), ptr(w0t), ptr(g1), ptr(w1t), ptr(relu_mask), ptr(relu_bits),
+                                               ptr(gin), m, k, n0, n1, current_stream()), "gts_linear_bwd_input_t_f32"))
     return gin
 
 

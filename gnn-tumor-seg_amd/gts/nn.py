@@ -161,6 +161,9 @@ def _side_stream(device):
 
 # GTS_CHAIN_GEMMS=0 keeps one launch per GEMM in the fused stack (A/B runs).
 CHAIN_LAYER_GEMMS = os.environ.get("GTS_CHAIN_GEMMS", "1") != "0"
+# GTS_RELU_BITS=0: the backward of the fused stack reads its ReLU masks from the saved activations (floats)
+# instead of the bit masks the forward GEMMs record (A/B runs).
+RELU_MASK_BITS = os.environ.get("GTS_RELU_BITS", "1") != "0"
 
 
 def _chainable(a0, w0, a1, w2):
@@ -193,6 +196,7 @@ class _SagePoolStack(torch.autograd.Function):
         n_layers = len(params) // 5
         h = x.contiguous()
         saved = []
+        hbits = None                      # h > 0 as bits (h is a ReLU output from layer 1 on): the backward's mask
         p = None                          # relu(fc_pool(h)) of the layer about to run, when already computed
         for i in range(n_layers):
             w_pool, b_pool, w_self, w_neigh, bias = params[5 * i:5 * i + 5]
@@ -202,13 +206,15 @@ class _SagePoolStack(torch.autograd.Function):
             m, arg = ops.spmm_max_fwd(g, p, want_arg=need_bwd, relu_input=True)   # p is not kept
             p = None
             nxt = params[5 * (i + 1):5 * (i + 1) + 2] if not last else None
+            obits = dense.relu_bits_empty(h.shape[0], w_self.shape[0], h.device) \
+                if RELU_MASK_BITS and need_bwd and not last and w_self.shape[0] % 64 == 0 else None
             if CHAIN_LAYER_GEMMS and nxt is not None and _chainable(h, w_self, m, nxt[0]):
                 # fc_self + fc_neigh of this layer and fc_pool of the next one in one launch
-                out, p = dense.linear_fwd_chain(h, w_self, m, w_neigh, bias, True, nxt[0], nxt[1], True)
+                out, p = dense.linear_fwd_chain(h, w_self, m, w_neigh, bias, True, nxt[0], nxt[1], True, relu_bits=obits)
             else:
-                out = dense.linear_fwd(h, w_self, m, w_neigh, bias=bias, relu=not last)
-            saved += [h, m, arg]
-            h = out
+                out = dense.linear_fwd(h, w_self, m, w_neigh, bias=bias, relu=not last, relu_bits=obits)
+            saved += [h, m, arg, hbits]
+            h, hbits = out, obits
         if need_bwd:
             ctx.g, ctx.n_layers = g, n_layers
             ctx.save_for_backward(*saved, *params)
@@ -218,7 +224,7 @@ class _SagePoolStack(torch.autograd.Function):
     def backward(ctx, gout):
         n = ctx.n_layers
         tensors = ctx.saved_tensors
-        acts, params = tensors[:3 * n], tensors[3 * n:]
+        acts, params = tensors[:4 * n], tensors[4 * n:]
         grads = [None] * (5 * n)
         g = gout.contiguous()            # gradient w.r.t. the pre-activation output of layer i
         gx = None
@@ -246,10 +252,10 @@ class _SagePoolStack(torch.autograd.Function):
                 for w, wt in zip(ws, dense.transpose_batch(ws)):
                     turned[id(w)] = wt
 
-        def igrad(g0, w0, g1=None, w1=None, relu_mask=None):
+        def igrad(g0, w0, g1=None, w1=None, relu_mask=None, relu_bits=None):
             if id(w0) in turned and (w1 is None or id(w1) in turned) and g0.is_contiguous():
                 return dense.linear_bwd_input_t(g0, turned[id(w0)], g1, turned[id(w1)] if w1 is not None else None,
-                                                relu_mask=relu_mask)
+                                                relu_mask=relu_mask, relu_bits=relu_bits)
             return dense.linear_bwd_input(g0, w0, g1, w1, relu_mask=relu_mask)
 
         def defer(grad_out, act, slot, bias_slot):
@@ -258,7 +264,7 @@ class _SagePoolStack(torch.autograd.Function):
 
         gm = None                         # g @ W_neigh of the layer about to run, when already computed
         for i in reversed(range(n)):
-            h, m, arg = acts[3 * i:3 * i + 3]
+            h, m, arg, hbits = acts[4 * i:4 * i + 4]
             w_pool, _b_pool, w_self, w_neigh, _bias = params[5 * i:5 * i + 5]
             if gm is None:
                 gm = igrad(g, w_neigh)
@@ -282,9 +288,9 @@ class _SagePoolStack(torch.autograd.Function):
                         and _chainable(g, w_self.t(), gp, below.t()):
                     # this layer's input gradient and the next one's g @ W_neigh in one launch
                     g, gm = dense.linear_bwd_input_chain_t(g, turned[id(w_self)], gp, turned[id(w_pool)], h,
-                                                           turned[id(below)])
+                                                           turned[id(below)], relu_bits=hbits)
                 else:
-                    g = igrad(g, w_self, gp, w_pool, relu_mask=h)
+                    g = igrad(g, w_self, gp, w_pool, relu_mask=h, relu_bits=hbits)
             elif ctx.needs_input_grad[1]:
                 gx = igrad(g, w_self, gp, w_pool)
         for problems in deferred.values():

@@ -202,10 +202,18 @@ int32_t gts_label_confusion_i16(const int16_t* pred, const int16_t* truth, int64
  *
  * forward:  out[m, n] = act( sum_k a0[m,k] w0[n,k] + (a1 ? sum_k a1[m,k] w1[n,k] : 0) + bias[n] )
  *   a0 [M,K0], w0 [N,K0], a1 [M,K1], w1 [N,K1] row-major (torch Linear layout); bias optional;
- *   relu != 0 applies max(., 0).  The pair form is fc_self(h) + fc_neigh(m) in one pass. */
+ *   relu != 0 applies max(., 0).  The pair form is fc_self(h) + fc_neigh(m) in one pass.
+ *   relu_bits (optional, n % 64 == 0, gts_relu_bits_bytes(m, n) bytes): out > 0 as one bit per element, written
+ *   while out is stored — the ReLU mask the input-gradient calls below can read instead of the floats of `out`
+ *   (1/32 of the bytes, and scalar loads that do not queue behind the epilogue's stores).  Layout: 64-bit word
+ *   ((col / 64) * ceil(m / 4) + row / 4) * 4 + e, bit 16 * (row % 4) + (col % 64) / 4, holds
+ *   out[row][64 * (col / 64) + 4 * ((col % 64) / 4) + e] > 0  (e = 0..3): one word = one wave-wide comparison of the
+ *   epilogue that stores four rows x 64 columns as 16-byte pieces, and the words of a wave's 80 rows are consecutive.
+ *   Bits of rows >= m are unspecified. */
+int64_t gts_relu_bits_bytes(int64_t m, int64_t n);
 int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const float* a1, const float* w1,
                            const float* bias, float* out, int64_t m, int64_t n, int64_t k0,
-                           int64_t k1, int32_t relu, void* stream);
+                           int64_t k1, int32_t relu, uint64_t* relu_bits, void* stream);
 /* input gradient:  gin[m, k] = sum_n g0[m,n] w0[n,k] + (g1 ? sum_n g1[m,n] w1[n,k] : 0)
  *   g0 [M,N0], w0 [N0,K], g1 [M,N1], w1 [N1,K].  relu_mask (optional, [M,K]): gin is zeroed
  *   where relu_mask <= 0, i.e. the ReLU backward of the layer that produced this input. */
@@ -214,10 +222,13 @@ int32_t gts_linear_bwd_input_f32(const float* g0, const float* w0, const float* 
                                  int64_t n0, int64_t n1, void* stream);
 /* the same input gradient from TRANSPOSED weights (w0t [K,N0], w1t [K,N1], e.g. made once per
  * backward pass by gts_transpose_batch_f32): both GEMM operands are then reduction-contiguous, the
- * forward kernel's form — bitwise the same sums in the same order as gts_linear_bwd_input_f32. */
+ * forward kernel's form — bitwise the same sums in the same order as gts_linear_bwd_input_f32.
+ * relu_bits (optional, k % 64 == 0; relu_mask must be given too): relu_mask > 0 in the bit layout above, as written by
+ * the forward call that produced relu_mask; the kernels that can use the bits never touch relu_mask, the others read
+ * its floats as before — the result is the same either way. */
 int32_t gts_linear_bwd_input_t_f32(const float* g0, const float* w0t, const float* g1, const float* w1t,
-                                   const float* relu_mask, float* gin, int64_t m, int64_t k,
-                                   int64_t n0, int64_t n1, void* stream);
+                                   const float* relu_mask, const uint64_t* relu_bits, float* gin, int64_t m,
+                                   int64_t k, int64_t n0, int64_t n1, void* stream);
 /* GATConv's projection with its attention scores (model/networks.py:46,52,56 -> dgl GATConv: feat_src = fc(h).view(N, H, D);
  * el = (feat_src * attn_l).sum(-1); er likewise):  ft [m, heads*dim] = h [m, k] w_fc^T,  el/er [m, heads] = <ft[n,h,:], attn_l/r[h,:]>.
  * Tall operands with dim % 64 == 0: the dot products ride in the GEMM epilogue (partials per 64 columns in `workspace`,
@@ -231,15 +242,16 @@ int32_t gts_gat_fc_scores_f32(const float* h, const float* w_fc, const float* at
  *   out2 [m, n2] = act2(out w2^T + bias2)                      exactly gts_linear_fwd_f32 on `out`
  * (SAGEConv-pool stack: fc_self + fc_neigh of layer L, then fc_pool of layer L+1 on the rows just produced).
  * The input-gradient form chains  gin = (g0 w0 (+ g1 w1)) (. mask)  and  gin2 = gin w2  on transposed weights
- * (w0t [k, n0], w1t [k, n1], w2t [k2, k]).  n (resp. k) must be a multiple of 4. */
+ * (w0t [k, n0], w1t [k, n1], w2t [k2, k]).  n (resp. k) must be a multiple of 4.  relu_bits: the mask bits of
+ * `out` (written) resp. of relu_mask (read), as in gts_linear_fwd_f32 / gts_linear_bwd_input_t_f32. */
 int32_t gts_linear_fwd_chain_f32(const float* a0, const float* w0, const float* a1, const float* w1,
                                  const float* bias, float* out, const float* w2, const float* bias2,
                                  float* out2, int64_t m, int64_t n, int64_t k0, int64_t k1, int32_t relu,
-                                 int64_t n2, int32_t relu2, void* stream);
+                                 int64_t n2, int32_t relu2, uint64_t* relu_bits, void* stream);
 int32_t gts_linear_bwd_input_chain_t_f32(const float* g0, const float* w0t, const float* g1,
-                                         const float* w1t, const float* relu_mask, float* gin,
-                                         const float* w2t, float* gin2, int64_t m, int64_t k, int64_t n0,
-                                         int64_t n1, int64_t k2, void* stream);
+                                         const float* w1t, const float* relu_mask, const uint64_t* relu_bits,
+                                         float* gin, const float* w2t, float* gin2, int64_t m, int64_t k,
+                                         int64_t n0, int64_t n1, int64_t k2, void* stream);
 /* dst[q][c, r] = src[q][r, c] for n_mats matrices of one shape [rows, cols] in one launch per 32
  * (src, dst: HOST arrays of device pointers).  Serves the transposed-weight form above: the
  * weights of a layer stack (torch Linear layout [out, in]) are turned once per backward pass. */

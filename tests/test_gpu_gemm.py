@@ -142,7 +142,7 @@ def test_rows240_narrow_output_through_the_c_abi(hip_lib):
     out = torch.full((m, n), float("nan"), device=DEV)
     try:
         assert hip_lib.gts_set_option(1, 9) == 0
-        assert hip_lib.gts_linear_fwd_f32(ptr(a), ptr(w), None, None, ptr(b), ptr(out), m, n, k, 0, 1, current_stream()) == 0
+        assert hip_lib.gts_linear_fwd_f32(ptr(a), ptr(w), None, None, ptr(b), ptr(out), m, n, k, 0, 1, None, current_stream()) == 0
     finally:
         hip_lib.gts_set_option(1, -1)
     want = (a.cpu().double() @ w.cpu().double().t() + b.cpu().double()).clamp(min=0)
@@ -302,3 +302,39 @@ def test_chained_layer_gemms_equal_two_calls_bit_for_bit(m, k0, k1, n, n2):
     gin, gin2 = dense.linear_bwd_input_chain_t(a0, w0, a1, w1, mask, w2)
     want = dense.linear_bwd_input_t(a0, w0, a1, w1, relu_mask=mask)
     assert torch.equal(gin, want) and torch.equal(gin2, dense.linear_bwd_input_t(want, w2))
+
+
+@pytest.mark.parametrize("m,k0,k1,n", [(60000, 256, 256, 256), (60000, 4, 4, 256), (49999, 132, 0, 128), (1000, 64, 64, 256),
+                                       (46083, 256, 0, 64), (7, 8, 0, 64)])
+@pytest.mark.parametrize("variant", [-1, 10, 9, 8])
+def test_relu_mask_as_bits_written_by_the_forward_and_read_by_the_input_gradient(hip_lib, m, k0, k1, n, variant):
+    """`relu_bits`: the forward GEMM records out > 0 as one bit per element (panel kernels: in their epilogue;
+    the other tiles: a pass of their own), and the transposed input gradient masked by those bits equals the one
+    masked by the floats, bit for bit, plain and chained."""
+    a0, w0 = _rand(m, k0, seed=1).to(DEV), _rand(n, k0, seed=2).to(DEV)
+    a1, w1 = (_rand(m, k1, seed=3).to(DEV), _rand(n, k1, seed=4).to(DEV)) if k1 else (None, None)
+    b, w2, b2 = _rand(n, seed=5).to(DEV), _rand(64, n, seed=6).to(DEV), _rand(64, seed=7).to(DEV)
+    try:
+        assert hip_lib.gts_set_option(1, variant) == 0
+        bits = dense.relu_bits_empty(m, n, DEV).fill_(-1)
+        out = dense.linear_fwd(a0, w0, a1, w1, bias=b, relu=True, relu_bits=bits)
+        assert torch.equal(out, dense.linear_fwd(a0, w0, a1, w1, bias=b, relu=True))
+        on = dense.unpack_relu_bits(bits, m, n)
+        assert on.shape == (m, n) and torch.equal(on, out > 0)
+        assert 0.2 < float(on.float().mean()) < 0.8              # a real mask, not all-on / all-off
+        bits2 = dense.relu_bits_empty(m, n, DEV).fill_(-1)
+        out_c, _ = dense.linear_fwd_chain(a0, w0, a1, w1, b, True, w2, b2, True, relu_bits=bits2)
+        assert torch.equal(out_c, out) and torch.equal(dense.unpack_relu_bits(bits2, m, n), on)
+        # consumer: g [m, n0] @ W^T-form weights [n, n0] masked by `out`
+        g0, wt = _rand(m, 64, seed=9).to(DEV), _rand(n, 64, seed=10).to(DEV)
+        want = dense.linear_bwd_input_t(g0, wt, relu_mask=out)
+        assert torch.equal(dense.linear_bwd_input_t(g0, wt, relu_mask=out, relu_bits=bits), want)
+        w3 = _rand(64, n, seed=11).to(DEV)
+        gin, gin2 = dense.linear_bwd_input_chain_t(g0, wt, None, None, out, w3, relu_bits=bits)
+        assert torch.equal(gin, want) and torch.equal(gin2, dense.linear_bwd_input_t(want, w3))
+    finally:
+        hip_lib.gts_set_option(1, -1)
+    with pytest.raises(dense._lib.GtsError):
+        dense.relu_bits_empty(m, 96, DEV)
+    with pytest.raises(dense._lib.GtsError, match="shapes do not match"):
+        dense.linear_fwd(a0, w0, a1, w1, bias=b, relu=True, relu_bits=bits[:-1])

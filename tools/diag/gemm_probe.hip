@@ -17,7 +17,10 @@ struct StampProbe {
       const size_t wg = (static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
       const size_t at = (wg * 4 + phase) * 2;
       g_probe[at] = __builtin_amdgcn_s_memrealtime();
-      g_probe[at + 1] = __builtin_amdgcn_s_memtime();
+      // phase 0 also records where the wave runs: HW_ID (wave / SIMD / CU / SE) | XCC_ID << 32
+      g_probe[at + 1] = phase == 0 ? (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(6164)) << 32) |
+                                         __builtin_amdgcn_s_getreg(63492)
+                                   : __builtin_amdgcn_s_memtime();
     }
   }
 };
@@ -29,7 +32,10 @@ struct WaveProbe {
       const size_t wg = static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x;
       const size_t at = (((wg * (blockDim.x >> 6)) + (threadIdx.x >> 6)) * 4 + phase) * 2;
       g_probe[at] = __builtin_amdgcn_s_memrealtime();
-      g_probe[at + 1] = __builtin_amdgcn_s_memtime();
+      // phase 0 also records where the wave runs: HW_ID (wave / SIMD / CU / SE) | XCC_ID << 32
+      g_probe[at + 1] = phase == 0 ? (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(6164)) << 32) |
+                                         __builtin_amdgcn_s_getreg(63492)
+                                   : __builtin_amdgcn_s_memtime();
     }
   }
 };

@@ -38,7 +38,10 @@ for dual in (False, True):
         lib.gts_probe_set_buffer(stamps.data_ptr())
         lib.gts_probe_linear_fwd(*args)
         torch.cuda.synchronize()
-        t = stamps.cpu().numpy().reshape(n_wg, waves, 4, 2)[..., 0].astype(np.float64) * 0.01
+        raw = stamps.cpu().numpy().reshape(n_wg, waves, 4, 2)
+        t = raw[..., 0].astype(np.float64) * 0.01
+        where = raw[:, 0, 0, 1]
+        xcc, se, cu = (where >> 32) & 15, (where >> 13) & 7, (where >> 8) & 15
         t0 = t[:, :, 0].min()
         start, main_end, end = t[:, :, 0] - t0, t[:, :, 2] - t0, t[:, :, 3] - t0
         print(f"{'pair' if dual else 'single'} A-hot={hot}: kernel span {end.max():.1f} us; wave start median {np.median(start):.1f}")
@@ -52,3 +55,11 @@ for dual in (False, True):
                   + f" us;  store phase median {np.median(end - main_end):.1f} us, p90 {np.percentile(end - main_end, 90):.1f}")
         print(f"   last reduction end per workgroup: median {np.median(main_end.max(1)):.1f}, max {main_end.max():.1f};"
               f" last store end per workgroup: median {np.median(end.max(1)):.1f}, max {end.max():.1f}", flush=True)
+        wg_end, wg_start = end.max(1), start.min(1)
+        print("   workgroup end percentiles 10/50/90/99/100: " + " ".join(f"{np.percentile(wg_end, q):.1f}" for q in (10, 50, 90, 99, 100))
+              + "; start percentiles 50/90/100: " + " ".join(f"{np.percentile(wg_start, q):.1f}" for q in (50, 90, 100))
+              + f"; corr(start, end) {np.corrcoef(wg_start, wg_end)[0, 1]:.2f}")
+        print("   per XCD (n, median end, max end): " + " ".join(
+            f"{x}:({int((xcc == x).sum())},{np.median(wg_end[xcc == x]):.1f},{wg_end[xcc == x].max():.1f})" for x in sorted(set(xcc.tolist()))))
+        cuid = xcc * 1000 + se * 16 + cu
+        print(f"   distinct (xcc, se, cu) ids {len(set(cuid.tolist()))} for {n_wg} workgroups", flush=True)
