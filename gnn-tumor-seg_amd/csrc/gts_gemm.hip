@@ -24,6 +24,8 @@
 // The reduction index consumed by MFMA step (g, j) on lane-half h is 8g + 4h + j for both
 // operands — a permutation of kk inside each 8-block, free for a sum, chosen so that the
 // contiguous operand needs ONE 16-byte LDS read per four MFMAs.
+#include <type_traits>
+
 #include "gts_rows.h"
 
 namespace gts {
@@ -632,8 +634,15 @@ struct PanelStage {   // one GEMM of the panel kernel: c[rows of the panel, rb] 
   const unsigned long long* bits_in;   // optional: `mask` as bits
 };
 
-template <int WM, int WN, int DEPTH>
+// What the epilogue of a stage does, as template bits: with kEpiRuntime every switch is read from the arguments
+// (any shape); without it the switches are compile-time facts and the output is whole 256-column blocks
+// (host-checked) — the epilogue of the layer-stack launches loses its ~50 uniform branches per 16 rows and
+// most of its code (the generic kernel is ~100 KB of instructions, more than the instruction cache).
+enum : int { kEpiBias = 1, kEpiRelu = 2, kEpiMaskBits = 4, kEpiBitsOut = 16, kEpiRuntime = 256, kEpiAbsent = -1 };
+
+template <int WM, int WN, int DEPTH, int F = kEpiRuntime>
 __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int sched, int m0, int n0, int row_end) {
+  constexpr bool G = (F & kEpiRuntime) != 0;
   constexpr int WTM = kR240 / WM, WTN = kC240 / WN, TM = WTM / 16, TN = WTN / 16;
   constexpr int R = DEPTH + 1;                     // register sets of fragments
   constexpr int kLd = WTN + 4, kStage = 16 * kLd;  // per-wave epilogue patch [16][WTN + 4]
@@ -709,25 +718,29 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
   // Epilogue as in gemm_rows240_kernel: a row of TN tiles (16 x WTN outputs) through the wave's LDS
   // patch, out as 16-byte row segments with bias / ReLU / mask applied as float4.
   float* stage = lds + wave * kStage;
-  const bool wide = (s.rb & 3) == 0 && (s.ldc & 3) == 0;
+  const bool wide = G ? (s.rb & 3) == 0 && (s.ldc & 3) == 0 : true;
   constexpr int kC4 = WTN / 4;                // float4 per patch row
   constexpr int kRowsPerIt = 64 / kC4;        // patch rows one pass of the wave covers
   const int c4 = (lane % kC4) * 4, rsub = lane / kC4;
   const int col = n0 + wn * WTN + c4;
-  const bool col_ok = col < s.rb;
+  const bool col_ok = G ? col < s.rb : true;
+  const bool has_bias = G ? s.bias != nullptr : (F & kEpiBias) != 0;
+  const bool relu = G ? s.relu != 0 : (F & kEpiRelu) != 0;
+  const bool scores = G ? s.sc_l != nullptr : false;
   v4f bias = {0.f, 0.f, 0.f, 0.f};
-  if (wide && s.bias != nullptr && col_ok) bias = *reinterpret_cast<const v4f*>(s.bias + col);
+  if (wide && has_bias && col_ok) bias = *reinterpret_cast<const v4f*>(s.bias + col);
   v4f sc_wl = {0.f, 0.f, 0.f, 0.f}, sc_wr = sc_wl;
-  if (wide && s.sc_l != nullptr && col_ok) {
+  if (wide && scores && col_ok) {
     sc_wl = *reinterpret_cast<const v4f*>(s.sc_l + col);
     sc_wr = *reinterpret_cast<const v4f*>(s.sc_r + col);
   }
   // ReLU masks as bits (GemmArgs::bits_out / bits_in): this wave's TM * 4 row groups of its 64-column block are
   // TM * 16 consecutive words of the [column block][row group][4] layout
   constexpr int kBitWords = TM * 16;
-  const bool bits_here = WTN == 64 && wide && n0 + wn * WTN < s.rb;
-  const bool bit_mask = bits_here && s.bits_in != nullptr && s.mask != nullptr;
-  const bool bits_wanted = bits_here && s.bits_out != nullptr;
+  static_assert(G || WTN == 64, "the compile-time epilogues keep mask bits: 64-column wave tiles");
+  const bool bits_here = G ? WTN == 64 && wide && n0 + wn * WTN < s.rb : true;
+  const bool bit_mask = G ? bits_here && s.bits_in != nullptr && s.mask != nullptr : (F & kEpiMaskBits) != 0;
+  const bool bits_wanted = G ? bits_here && s.bits_out != nullptr : (F & kEpiBitsOut) != 0;
   const size_t bits_at = (static_cast<size_t>((n0 + wn * WTN) >> 6) * ((s.ra + 3) >> 2) + ((m0 + wm * WTM) >> 2)) * 4;
   unsigned long long* bit_words = reinterpret_cast<unsigned long long*>(lds + WM * WN * kStage) + wave * kBitWords;
 #pragma unroll
@@ -735,7 +748,7 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
     const int row_base = m0 + wm * WTM + tm * 16;
     if (wide) {
       v4f mk[16 / kRowsPerIt];
-      const bool float_mask = s.mask != nullptr && !bit_mask;
+      const bool float_mask = G ? s.mask != nullptr && !bit_mask : false;
       if (float_mask) {
 #pragma unroll
         for (int it = 0; it < 16 / kRowsPerIt; ++it) {
@@ -762,7 +775,7 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
           for (int e = 0; e < 4; ++e) val[e] = (words[e] >> lane) & 1ull ? val[e] : 0.f;
         }
         if (row < row_end && col_ok) {
-          if (s.relu) {
+          if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
           }
@@ -771,7 +784,7 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
             for (int e = 0; e < 4; ++e) val[e] = mk[it][e] > 0.f ? val[e] : 0.f;
           }
           v4f* dst = reinterpret_cast<v4f*>(s.c + static_cast<size_t>(row) * s.ldc + col);
-          if (sched & 2) __builtin_nontemporal_store(val, dst);
+          if (G && (sched & 2)) __builtin_nontemporal_store(val, dst);
           else *dst = val;
         }
         if (bits_wanted) {   // one wave-wide comparison per element slot = one word; collected in LDS, stored once
@@ -779,7 +792,7 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
           const unsigned long long w2 = __ballot(val[2] > 0.f), w3 = __ballot(val[3] > 0.f);
           if (lane < 4) bit_words[(tm * (16 / kRowsPerIt) + it) * 4 + lane] = lane == 0 ? w0 : lane == 1 ? w1 : lane == 2 ? w2 : w3;
         }
-        if (s.sc_l != nullptr) {   // rb is a multiple of WTN here: every lane's columns are real
+        if (scores) {   // rb is a multiple of WTN here: every lane's columns are real
           float pl = (val[0] * sc_wl[0] + val[1] * sc_wl[1]) + (val[2] * sc_wl[2] + val[3] * sc_wl[3]);
           float pr = (val[0] * sc_wr[0] + val[1] * sc_wr[1]) + (val[2] * sc_wr[2] + val[3] * sc_wr[3]);
 #pragma unroll
@@ -820,7 +833,7 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
   }
 }
 
-template <int WM, int WN, int DEPTH, class Probe = NoProbe>
+template <int WM, int WN, int DEPTH, class Probe = NoProbe, int F1 = kEpiRuntime, int F2 = kEpiRuntime>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_kernel(const GemmArgs p) {
   constexpr int WTN = kC240 / WN;
   static_assert((kR240 / WM) % 16 == 0 && WTN % 16 == 0 && WTN % 4 == 0 && (WM * WN) % 4 == 0, "wave tiles are whole 16x16 tiles");
@@ -837,13 +850,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
   s0.ra = p.ra, s0.rb = p.rb, s0.ldc = p.ldc, s0.relu = p.relu, s0.c = p.c, s0.bias = p.bias, s0.mask = p.mask;
   s0.sc_l = p.sc_l, s0.sc_r = p.sc_r, s0.sc_el = p.sc_el, s0.sc_er = p.sc_er;
   s0.bits_out = p.bits_out, s0.bits_in = p.bits_in;
-  panel_stage<WM, WN, DEPTH>(s0, lds, p.sched, m0, n0, row_end);
+  panel_stage<WM, WN, DEPTH, F1>(s0, lds, p.sched, m0, n0, row_end);
   Probe::mark(2);
   // With c2 set a second GEMM follows in the same launch: the rows this workgroup has just stored are
   // its A operand (the next layer's fc_pool behind fc_self + fc_neigh; the next input gradient behind
   // this one) — one launch, one cold start and one output burst less per layer, and the operand
   // comes back out of this CU's own L2 slice.
-  if (p.c2 != nullptr) {
+  if (F2 != kEpiAbsent && ((F2 & kEpiRuntime) == 0 || p.c2 != nullptr)) {
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's rows of c are in memory ...
     __threadfence_block();
     __syncthreads();                       // ... and so are every other wave's, before any is read back
@@ -852,7 +865,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
     s1.lda[0] = s1.lda[1] = p.ldc, s1.ldb[0] = s1.ldb[1] = p.ldb2;
     s1.kseg[0] = p.rb, s1.kseg[1] = 0;
     s1.ra = p.ra, s1.rb = p.rb2, s1.ldc = p.ldc2, s1.relu = p.relu2, s1.c = p.c2, s1.bias = p.bias2, s1.mask = nullptr;
-    panel_stage<WM, WN, DEPTH>(s1, lds, p.sched, m0, 0, row_end);
+    panel_stage<WM, WN, DEPTH, F2 == kEpiAbsent ? kEpiRuntime : F2>(s1, lds, p.sched, m0, 0, row_end);
   }
   Probe::mark(3);
 }
@@ -862,6 +875,26 @@ int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
   dim3 grid((p.ra + kR240 - 1) / kR240, (p.rb + kC240 - 1) / kC240, 1);
   GemmArgs q = p;
   q.sched = g_gemm_sched;
+  if constexpr (WM == 3 && WN == 4 && DEPTH == 1 && std::is_same<Probe, NoProbe>::value) {
+    // the launches of the SAGE-pool layer stack at its 256-wide layers: compile-time epilogues
+    const bool whole = p.rb % kC240 == 0 && p.ldc % 4 == 0 && p.sc_l == nullptr && (p.mask == nullptr || p.bits_in != nullptr) &&
+                       (p.c2 == nullptr || (p.rb2 % kC240 == 0 && p.ldc2 % 4 == 0)) && !(q.sched & 2) && !(q.sched & 4);
+    const int f1 = (p.bias ? kEpiBias : 0) | (p.relu ? kEpiRelu : 0) | (p.mask ? kEpiMaskBits : 0) | (p.bits_out ? kEpiBitsOut : 0);
+    const int f2 = p.c2 == nullptr ? kEpiAbsent : (p.bias2 ? kEpiBias : 0) | (p.relu2 ? kEpiRelu : 0);
+    constexpr int kFwd = kEpiBias | kEpiRelu;
+    if (whole && f1 == (kFwd | kEpiBitsOut) && f2 == kFwd) {          // fc_self + fc_neigh, then the next fc_pool (training)
+      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kFwd | kEpiBitsOut, kFwd><<<grid, 768, 0, st>>>(q);
+      return launch_status();
+    }
+    if (whole && f1 == kEpiMaskBits && f2 == 0) {                     // a layer's input gradient, then g @ W_neigh below
+      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kEpiMaskBits, 0><<<grid, 768, 0, st>>>(q);
+      return launch_status();
+    }
+    if (whole && f1 == 0 && f2 == kEpiAbsent) {                       // a plain product (g @ W_neigh of the top layer)
+      gemm_panel_direct_kernel<3, 4, 1, NoProbe, 0, kEpiAbsent><<<grid, 768, 0, st>>>(q);
+      return launch_status();
+    }
+  }
   gemm_panel_direct_kernel<WM, WN, DEPTH, Probe><<<grid, 64 * WM * WN, 0, st>>>(q);
   return launch_status();
 }

@@ -294,7 +294,9 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
 #define GTS_OPT_SPMM_STREAMING 5     /* K1/K2: bit 0 = non-temporal stores of write-once rows, bit 1 = non-temporal
                                         loads of read-once rows (K2's relu_src); -1 = per-kernel default */
 #define GTS_OPT_GEMM_SCHED 7  /* K11 scheduling bits (default 1): 1 = s_setprio by progress inside a reduction tile (LDS kernels),
-                                2 = non-temporal stores of the output panel (direct-to-fragment kernels; no gain measured) */
+                                2 = non-temporal stores of the output panel (direct-to-fragment kernels; no gain measured),
+                                4 = the direct-to-fragment kernels keep every epilogue switch a run-time argument (the generic
+                                    instantiation) instead of the compile-time epilogues of the layer-stack launches (A/B runs) */
 int32_t gts_set_option(int32_t option, int32_t value);
 
 #ifdef __cplusplus
