@@ -1,5 +1,8 @@
-"""What bounds the panel kernel (variant 10)?  Times it with GTS_OPT_GEMM_SCHED what-if bits (results are wrong
-with bits 16/32 set: the operand loads stop walking along the reduction, so they always hit in L1)."""
+"""Launch times of the panel kernel (variant 10) at the C2 layer shape under GTS_OPT_GEMM_SCHED settings
+(argv[1] = comma-separated values; 1 = default, 3 = non-temporal stores, 5 = generic epilogue): forward single /
+pair / pair with mask bits written, and the transposed input gradient without mask, with the float mask and with
+the bit mask.  The round-2 what-if experiments (operand loads pinned to one reduction group = always L1 hits; no
+epilogue; no mask read) patched the kernel temporarily; their results are in profiles/r02_panel_whatif.log."""
 import sys
 
 sys.path.insert(0, "gnn-tumor-seg_amd")
