@@ -162,6 +162,42 @@ def test_c2_full_size_forward_loss_and_gradients_match_oracle():
     _check_against_oracles(ref, ref64, mine, tg, g, x, y)
 
 
+@pytest.mark.timeout(600)
+def test_c2_backward_is_the_same_with_bit_masks_float_masks_and_generic_epilogues(hip_lib):
+    """The switches of the 256-wide layer launches change where the ReLU masks come from (bits recorded by the
+    forward GEMM vs the floats of the saved activation) and which instantiation runs (compile-time vs run-time
+    epilogue), never a sum: loss and every gradient are bitwise the same."""
+    from gts import nn as gnn
+
+    hp = HP(4, 4, [256] * 7, None, None)
+    g, x, y = _lattice_batch(4)
+    torch.manual_seed(0)
+    mine = init_graph_net("GSpool", hp).to(DEV)
+    gd, xd, yd, w = g.to(DEV), x.to(DEV), y.to(DEV), torch.tensor(CLASS_W, device=DEV)
+
+    def run():
+        mine.zero_grad(set_to_none=True)
+        loss = F.cross_entropy(mine(gd, xd), yd, weight=w)
+        loss.backward()
+        return float(loss), [p.grad.clone() for p in mine.parameters()]
+
+    base = run()
+    assert all(torch.isfinite(t).all() for t in base[1])
+    try:
+        gnn.RELU_MASK_BITS = False
+        floats = run()
+        gnn.RELU_MASK_BITS = True
+        assert hip_lib.gts_set_option(7, 5) == 0          # GTS_OPT_GEMM_SCHED bit 4: generic epilogues
+        generic = run()
+    finally:
+        gnn.RELU_MASK_BITS = True
+        hip_lib.gts_set_option(7, 1)
+    for other in (floats, generic):
+        assert other[0] == base[0]
+        for a, b in zip(base[1], other[1]):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.timeout(1200)
 @pytest.mark.parametrize("m,count", [(60000, 19), (120000, 19)])
 def test_deferred_weight_gradient_launch_at_full_size(hip_lib, m, count):
