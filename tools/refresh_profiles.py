@@ -1,0 +1,72 @@
+"""Copy the judged artefacts of one `tools/gpu_validate.sh <tag>` session from gpurun_out/<tag>/ into profiles/
+(bench lines, rocprof kernel stats + markdown summaries, PMC traffic, kernel-only means read by bench.py).
+Usage: python tools/refresh_profiles.py <tag> [round prefix, default r02]"""
+import csv
+import glob
+import io
+import json
+import os
+import shutil
+import sys
+from contextlib import redirect_stdout
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import summarize_rocprof  # noqa: E402
+
+tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+src, dst = f"gpurun_out/{tag}", "profiles"
+
+
+def last_json_line(path):
+    lines = [ln for ln in open(path).read().splitlines() if ln.startswith("{")]
+    return lines[-1]
+
+
+for name in ("c2", "c3", "c5", "c2_b8", "c2_b32"):
+    with open(f"{dst}/{rnd}_bench_{name}.json", "w") as fh:
+        fh.write(last_json_line(f"{src}/bench_{name}.json") + "\n")
+for name in ("pmc_traffic.json", "pmc_traffic_b32.json"):
+    shutil.copy(f"{src}/{name}", f"{dst}/{name}")
+shutil.copy(f"{src}/aux_kernels.jsonl", f"{dst}/{rnd}_aux_kernels.jsonl")
+
+
+def stats(prof_dir, out_stem, steps, title):
+    path = glob.glob(f"{src}/{prof_dir}/**/*kernel_stats.csv", recursive=True)[0]
+    out_csv = f"{dst}/{out_stem}_kernel_stats.csv"
+    shutil.copy(path, out_csv)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        summarize_rocprof.main(out_csv, steps, title)
+    open(f"{dst}/{out_stem}_summary.md", "w").write(buf.getvalue())
+    return {r["Name"]: r for r in csv.DictReader(open(out_csv))}
+
+
+def mean_us(rows, needle):
+    hit = [r for n, r in rows.items() if all(s in n for s in needle)]
+    calls = sum(int(r["Calls"]) for r in hit)
+    return round(sum(float(r["TotalDurationNs"]) for r in hit) / calls / 1e3, 2), calls
+
+
+c2 = stats("prof", f"{rnd}_bench", 65, f"Round {rnd[1:]}: bench.py --steps 20 --warmup 5 --blocks 2 (C2; 5 warm-up + 2 timed blocks + 1 "
+           "instrumented block = 65 steps)")
+c3 = stats("prof_c3", f"{rnd}_bench_c3", 12, f"Round {rnd[1:]}: bench.py --config c3 --steps 5 --warmup 2 --blocks 1 (GAT 4x4x256; 2 + 5 + 5 = 12 steps)")
+b32 = stats("prof_b32", f"{rnd}_bench_c2_b32", 7, f"Round {rnd[1:]}: bench.py --graphs-per-gpu 32 --steps 3 --warmup 1 --blocks 1 (1 + 3 + 3 = 7 steps)")
+stats("prof_aux", f"{rnd}_aux", 1, f"Round {rnd[1:]}: tools/measure_aux_kernels.py (streaming kernels around the network)")
+panel, panel_calls = mean_us(c2, ("gemm_panel_direct_kernel<3, 4, 1",))
+avg = {
+    "source": f"profiles/{rnd}_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 5 --blocks 2 "
+              "--no-cpu-baseline`, kernel-only durations)",
+    "spmm_max_fwd_f256_avg_us": mean_us(c2, ("spmm_max_fwd_kernel<4, 64, 1>",))[0],
+    "spmm_max_bwd_f256_avg_us": mean_us(c2, ("spmm_max_bwd_kernel<4, 64, 1>",))[0],
+    "gemm_panel_direct_avg_us": panel,
+    "gemm_panel_direct_calls": panel_calls,
+    "gemm_wgrad_256x256_avg_us": mean_us(c2, ("gemm_kernel<256, 256, 4, 4, false, false, true",))[0],
+    "b32_source": f"profiles/{rnd}_bench_c2_b32_kernel_stats.csv (--graphs-per-gpu 32)",
+    "b32_spmm_max_fwd_f256_avg_us": mean_us(b32, ("spmm_max_fwd_kernel<4, 64, 1>",))[0],
+    "b32_spmm_max_bwd_f256_avg_us": mean_us(b32, ("spmm_max_bwd_kernel<4, 64, 1>",))[0],
+    "c3_source": f"profiles/{rnd}_bench_c3_kernel_stats.csv (--config c3)",
+    "gat_fwd_avg_us": mean_us(c3, ("gat_fwd_kernel<4, 64>",))[0],
+}
+json.dump(avg, open(f"{dst}/rocprof_kernel_avg.json", "w"), indent=1)
+print(json.dumps(avg, indent=1))
