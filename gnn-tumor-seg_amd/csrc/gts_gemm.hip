@@ -1391,8 +1391,144 @@ __global__ __launch_bounds__(256) void relu_bits_kernel(const float* __restrict_
   if (lane < 4) bits[(cb * groups + group) * 4 + lane] = lane == 0 ? w0 : lane == 1 ? w1 : lane == 2 ? w2 : w3;
 }
 
+// A few inputs to a few outputs per node (fc_pool of the first layer: 4 -> 4 on 60 000 rows): one lane per row,
+// the row's <= 16 inputs as 16-byte loads (consecutive lanes = consecutive rows: contiguous), the weights at
+// wave-uniform addresses, fused multiply-adds in reduction order.  A 128 x 64 MFMA tile would multiply zeros for
+// 23 us here; this is 0.5 MB of traffic.
+template <int N>
+__global__ __launch_bounds__(256) void tiny_fwd_kernel(const GemmArgs p) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= p.ra) return;
+  float acc[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) acc[n] = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+  for (int seg = 0; seg < 2; ++seg) {
+    const float* a = p.a[seg] + static_cast<size_t>(row) * p.lda[seg];
+    for (int k = 0; k < p.kseg[seg]; k += 4) {
+      const v4f x = *reinterpret_cast<const v4f*>(a + k);
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        const v4f w = *reinterpret_cast<const v4f*>(p.b[seg] + n * p.ldb[seg] + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[n] = __builtin_fmaf(x[e], w[e], acc[n]);
+      }
+    }
+  }
+  float* out = p.c + static_cast<size_t>(row) * p.ldc;
+#pragma unroll
+  for (int n = 0; n < N; n += 4) {
+    v4f o = {acc[n], acc[n + 1], acc[n + 2], acc[n + 3]};
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+    }
+    *reinterpret_cast<v4f*>(out + n) = o;
+  }
+}
+
+// Wide inputs to 4 or 8 outputs per node (the classifier layer: 256 + 256 -> 4; g @ W_neigh of the first layer:
+// 256 -> 4): HBM-bound row streaming.  A wave takes four rows at a time; lane l holds reduction indices
+// 4 l .. 4 l + 3 (+ 256 per further chunk) of each row and of every weight row, accumulates its partial dot
+// products in a fixed order and the 64 partials meet in an xor butterfly — the same sum for a row whatever
+// the batch holds.  (The 128 x 64 MFMA tile reads the same bytes at 3.1 TB/s: 40 us for the pair at C2.)
+template <int N, bool BKC>
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const GemmArgs p) {
+  constexpr int R = 4;
+  const int lane = threadIdx.x & 63;
+  const long long wave = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const long long row0 = wave * R;
+  if (row0 >= p.ra) return;
+  float acc[R][N];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[r][n] = 0.f;
+#pragma unroll
+  for (int seg = 0; seg < 2; ++seg) {
+    const int kseg = p.kseg[seg];
+    for (int k = 4 * lane; k < kseg; k += 256) {
+      v4f w[N];   // w[n][e] = B(n, k + e)
+      if constexpr (BKC) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) w[n] = *reinterpret_cast<const v4f*>(p.b[seg] + static_cast<size_t>(n) * p.ldb[seg] + k);
+      } else {      // weights [K, N] with ldb == N: the four reduction rows of this lane are 16 N contiguous bytes
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int n4 = 0; n4 < N; n4 += 4) {
+            const v4f t = *reinterpret_cast<const v4f*>(p.b[seg] + static_cast<size_t>(k + e) * p.ldb[seg] + n4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[n4 + j][e] = t[j];
+          }
+      }
+      v4f x[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        x[r] = row0 + r < p.ra ? *reinterpret_cast<const v4f*>(p.a[seg] + static_cast<size_t>(row0 + r) * p.lda[seg] + k)
+                               : v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[r][n] = __builtin_fmaf(x[r][e], w[n][e], acc[r][n]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[r][n] += __shfl_xor(acc[r][n], o, kWave);
+  // lane r * N / 4 + n / 4 stores the float4 (r, n..n+3): every lane holds every total
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int n = 0; n < N; n += 4) {
+      if (lane == r * (N / 4) + n / 4 && row0 + r < p.ra) {
+        v4f o = {acc[r][n], acc[r][n + 1], acc[r][n + 2], acc[r][n + 3]};
+        if (p.bias != nullptr) o += *reinterpret_cast<const v4f*>(p.bias + n);
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        *reinterpret_cast<v4f*>(p.c + static_cast<size_t>(row0 + r) * p.ldc + n) = o;
+      }
+    }
+}
+
+template <bool BKC>
+inline bool skinny_forward(const GemmArgs& p) {
+  const bool automatic = BKC ? g_fwd_variant < 0 : g_igrad_variant <= 1;   // no tile variant forced (the input gradient's default is 1)
+  return automatic && (p.rb == 4 || p.rb == 8) && p.ldc == p.rb && p.kseg[0] + p.kseg[1] >= 64 && p.mask == nullptr &&
+         p.c2 == nullptr && p.sc_l == nullptr && p.bits_out == nullptr &&
+         (BKC || (p.ldb[0] == p.rb && (p.kseg[1] == 0 || p.ldb[1] == p.rb)));
+}
+
+inline bool tiny_forward(const GemmArgs& p) {
+  return (p.rb == 4 || p.rb == 8) && p.ldc == p.rb && p.kseg[0] + p.kseg[1] <= 16 && p.mask == nullptr && p.c2 == nullptr &&
+         p.sc_l == nullptr && p.bits_out == nullptr && g_fwd_variant < 0;
+}
+
 template <bool AKC, bool BKC>
 int launch_plain_tiles(const GemmArgs& p, int variant, hipStream_t st) {
+  if constexpr (AKC && BKC) {
+    if (tiny_forward(p)) {
+      const unsigned blocks = static_cast<unsigned>((p.ra + 255) / 256);
+      if (p.rb == 4) tiny_fwd_kernel<4><<<blocks, 256, 0, st>>>(p);
+      else tiny_fwd_kernel<8><<<blocks, 256, 0, st>>>(p);
+      return launch_status();
+    }
+  }
+  if constexpr (AKC) {
+    if (skinny_forward<BKC>(p)) {
+      const unsigned blocks = static_cast<unsigned>((p.ra + 15) / 16);   // four waves of four rows
+      if (p.rb == 4) skinny_fwd_kernel<4, BKC><<<blocks, 256, 0, st>>>(p);
+      else skinny_fwd_kernel<8, BKC><<<blocks, 256, 0, st>>>(p);
+      return launch_status();
+    }
+  }
   if (p.rb <= 64) return launch_tiles<128, 64, 2, 2, AKC, BKC>(p, 1, 1, st);
   if (p.rb <= 128) return launch_tiles<128, 128, 2, 2, AKC, BKC>(p, 1, 1, st);
   switch (variant) {
@@ -1546,6 +1682,15 @@ extern "C" int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const fl
   p.bits_out = reinterpret_cast<unsigned long long*>(relu_bits);
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
   return launch_plain<true, true>(p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t gts_relu_bits_pay(int64_t m, int64_t n) {
+  using namespace gts;
+  if (m <= 0 || n <= 0 || n % 64 != 0 || m >= (1LL << 31) || n >= (1 << 20)) return 0;
+  GemmArgs p{};
+  p.ra = static_cast<int>(m), p.rb = static_cast<int>(n);
+  const int variant = pick_plain_variant<true, true>(p);
+  return variant >= 10 && variant <= 12 ? 1 : 0;
 }
 
 extern "C" int64_t gts_relu_bits_bytes(int64_t m, int64_t n) {

@@ -42,6 +42,7 @@ SIGNATURES = {
     "gts_label_confusion_i16": [_p, _p, _p, _p, _i64, _i64, _p],
     "gts_linear_fwd_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p, _p],
     "gts_relu_bits_bytes": [_i64, _i64],
+    "gts_relu_bits_pay": [_i64, _i64],
     "gts_linear_bwd_input_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "gts_linear_bwd_input_t_f32": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "gts_transpose_batch_f32": [_p, _p, _i32, _i64, _i64, _p],

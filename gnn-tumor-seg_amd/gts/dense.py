@@ -95,6 +95,12 @@ def relu_bits_empty(m, n, device):
     return torch.empty(nbytes // 8, dtype=torch.int64, device=device)
 
 
+def relu_bits_pay(m, n):
+    """True when the GEMM launches of an [m, n] activation keep the mask bits inside their epilogues (tall operands);
+    otherwise the bits would cost a pass of their own and the float mask is the better choice."""
+    return _lib.load().gts_relu_bits_pay(m, n) == 1
+
+
 def _chk_bits(bits, m, n, what):
     if bits is None:
         return

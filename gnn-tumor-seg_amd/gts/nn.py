@@ -207,7 +207,7 @@ class _SagePoolStack(torch.autograd.Function):
             p = None
             nxt = params[5 * (i + 1):5 * (i + 1) + 2] if not last else None
             obits = dense.relu_bits_empty(h.shape[0], w_self.shape[0], h.device) \
-                if RELU_MASK_BITS and need_bwd and not last and w_self.shape[0] % 64 == 0 else None
+                if RELU_MASK_BITS and need_bwd and not last and dense.relu_bits_pay(h.shape[0], w_self.shape[0]) else None
             if CHAIN_LAYER_GEMMS and nxt is not None and _chainable(h, w_self, m, nxt[0]):
                 # fc_self + fc_neigh of this layer and fc_pool of the next one in one launch
                 out, p = dense.linear_fwd_chain(h, w_self, m, w_neigh, bias, True, nxt[0], nxt[1], True, relu_bits=obits)

@@ -211,6 +211,9 @@ int32_t gts_label_confusion_i16(const int16_t* pred, const int16_t* truth, int64
  *   epilogue that stores four rows x 64 columns as 16-byte pieces, and the words of a wave's 80 rows are consecutive.
  *   Bits of rows >= m are unspecified. */
 int64_t gts_relu_bits_bytes(int64_t m, int64_t n);
+/* 1 when the launches for an [m, n] output would write / read these bits inside their epilogues (the panel kernels of
+ * the tall shapes); 0 when asking for them would only add a pass (callers then pass no relu_bits at all). */
+int32_t gts_relu_bits_pay(int64_t m, int64_t n);
 int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const float* a1, const float* w1,
                            const float* bias, float* out, int64_t m, int64_t n, int64_t k0,
                            int64_t k1, int32_t relu, uint64_t* relu_bits, void* stream);

@@ -26,7 +26,8 @@ def _check(got, want64, bound64):
 
 
 SHAPES = [(1, 4, 4), (37, 4, 8), (128, 256, 4), (129, 4, 256), (300, 256, 256), (1000, 20, 256),
-          (515, 256, 260), (64, 8, 4), (2049, 128, 64), (250, 300, 132)]
+          (515, 256, 260), (64, 8, 4), (2049, 128, 64), (250, 300, 132), (60000, 4, 4), (59999, 8, 8),
+          (60000, 256, 4), (59999, 260, 8), (5, 64, 4), (4097, 1024, 8), (60000, 4, 256)]
 
 
 @pytest.mark.parametrize("m,k,n", SHAPES)
@@ -334,6 +335,7 @@ def test_relu_mask_as_bits_written_by_the_forward_and_read_by_the_input_gradient
         assert torch.equal(gin, want) and torch.equal(gin2, dense.linear_bwd_input_t(want, w3))
     finally:
         hip_lib.gts_set_option(1, -1)
+    assert dense.relu_bits_pay(60000, 256) and not dense.relu_bits_pay(1000, 256) and not dense.relu_bits_pay(60000, 100)
     with pytest.raises(dense._lib.GtsError):
         dense.relu_bits_empty(m, 96, DEV)
     with pytest.raises(dense._lib.GtsError, match="shapes do not match"):
