@@ -29,6 +29,31 @@ __device__ __forceinline__ float group_max(float x) {
   return x;
 }
 
+// epilogue of GATConv: + res_fc(h) + bias, then the activation (ELU), all on the way out
+template <int VEC>
+__device__ __forceinline__ void gat_row_epilogue(const float (&acc)[VEC], float* __restrict__ out, const float* __restrict__ bias,
+                                                 const float* __restrict__ residual, int act, int r, int h, int dim, int c,
+                                                 bool active) {
+  Vec<VEC> o;
+#pragma unroll
+  for (int t = 0; t < VEC; ++t) o.v[t] = acc[t];
+  if (residual != nullptr) {
+    const Vec<VEC> rs = Vec<VEC>::load(residual + static_cast<size_t>(r) * dim + c);
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) o.v[t] += rs.v[t];
+  }
+  if (bias != nullptr) {
+    const Vec<VEC> bs = Vec<VEC>::load(bias + static_cast<size_t>(h) * dim + c);
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) o.v[t] += bs.v[t];
+  }
+  if (act == 1) {
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) o.v[t] = o.v[t] > 0.0f ? o.v[t] : expm1f(o.v[t]);
+  }
+  if (active) o.store(out + static_cast<size_t>(r) * dim + c);
+}
+
 // ------------------------------------------------------------------ forward
 template <int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
@@ -44,6 +69,50 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
     const int v = r / heads, h = r - v * heads;
     const int beg = indptr[v], end = indptr[v + 1];
     const float er_v = er[r];
+    if constexpr (LPR == kWave) {
+      // One wave per (node, head) and at most 64 in-edges: lane k keeps edge k's source id, score and weight, so
+      // the wave's life is three memory round trips (row extent -> edge ids -> scores + source slices) instead
+      // of seven (ids and scores were fetched again for the denominator and once more for the gather).  Same
+      // arithmetic in the same order as the general path below.
+      const int deg = end - beg;
+      if (deg <= kWave) {
+        const bool mine = gl < deg;
+        const int idx = mine ? indices[beg + gl] : 0;
+        const float el_u = mine ? el[static_cast<size_t>(idx) * heads + h] : 0.0f;
+        float w = 0.0f;
+        bool have_weights = false;
+        for_columns<VEC, LPR>(dim, [&](int c, bool active) {
+          float acc[VEC];
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) acc[t] = 0.0f;
+          for_chunks<LPR>(0, deg, [&](auto cnt_c, int k0) {
+            constexpr int CNT = decltype(cnt_c)::value;
+            Vec<VEC> val[CNT];
+#pragma unroll
+            for (int j = 0; j < CNT; ++j) {
+              const size_t urow = static_cast<size_t>(__builtin_amdgcn_readlane(idx, k0 + j)) * heads + h;
+              val[j] = Vec<VEC>::load(ft + urow * dim + c);
+            }
+            if (!have_weights) {   // the softmax of the row, while the first source slices are on their way
+              const float score = mine ? leaky(el_u + er_v, slope) : -INFINITY;
+              const float m = group_max<LPR>(score);
+              const float den = group_sum<LPR>(mine ? expf(score - m) : 0.0f);
+              w = mine ? expf(score - m) / den : 0.0f;
+              if (mine) attn[static_cast<size_t>(beg + gl) * heads + h] = w;
+              have_weights = true;
+            }
+#pragma unroll
+            for (int j = 0; j < CNT; ++j) {
+              const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), k0 + j));
+#pragma unroll
+              for (int t = 0; t < VEC; ++t) acc[t] += a * val[j].v[t];
+            }
+          });
+          gat_row_epilogue<VEC>(acc, out, bias, residual, act, r, h, dim, c, active);
+        });
+        continue;
+      }
+    }
     // pass 1: row maximum and softmax denominator; the group's lanes stride over the row's
     // edges and combine with an xor butterfly (all lanes of a group share r: convergent)
     float m = -INFINITY;
@@ -80,25 +149,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
           }
         }
       });
-      // epilogue of GATConv: + res_fc(h) + bias, then the activation (ELU), all on the way out
-      Vec<VEC> o;
-#pragma unroll
-      for (int t = 0; t < VEC; ++t) o.v[t] = acc[t];
-      if (residual != nullptr) {
-        const Vec<VEC> rs = Vec<VEC>::load(residual + static_cast<size_t>(r) * dim + c);
-#pragma unroll
-        for (int t = 0; t < VEC; ++t) o.v[t] += rs.v[t];
-      }
-      if (bias != nullptr) {
-        const Vec<VEC> bs = Vec<VEC>::load(bias + static_cast<size_t>(h) * dim + c);
-#pragma unroll
-        for (int t = 0; t < VEC; ++t) o.v[t] += bs.v[t];
-      }
-      if (act == 1) {
-#pragma unroll
-        for (int t = 0; t < VEC; ++t) o.v[t] = o.v[t] > 0.0f ? o.v[t] : expm1f(o.v[t]);
-      }
-      if (active) o.store(out + static_cast<size_t>(r) * dim + c);
+      gat_row_epilogue<VEC>(acc, out, bias, residual, act, r, h, dim, c, active);
     });
   }
 }
@@ -155,6 +206,52 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(
     }
     float dot_sum = 0.0f;  // sum_j a_j ga_j
     if constexpr (LPR == kWave) {
+      const int deg = end - beg;
+      if (live && deg <= kWave) {
+        // lane k keeps edge k's id, weight, score and dot product: no per-edge scalar is fetched twice and the
+        // closing per-edge formula runs on all edges at once instead of one lane walking them with dependent loads
+        const bool mine = gl < deg;
+        const int idx = mine ? indices[beg + gl] : 0;
+        const size_t my_pos = static_cast<size_t>(beg + gl) * heads + h;
+        const float a_l = mine ? attn[my_pos] : 0.0f;
+        const float pre = mine ? el[static_cast<size_t>(idx) * heads + h] + er[r] : 0.0f;
+        float ga = 0.0f;
+        for_chunks<LPR>(0, deg, [&](auto cnt_c, int k0) {
+          constexpr int CNT = decltype(cnt_c)::value;
+          float part[CNT];
+#pragma unroll
+          for (int j = 0; j < CNT; ++j) part[j] = 0.0f;
+          for (int c0 = 0; c0 < dim; c0 += LPR * VEC) {
+            const int c = c0 + gl * VEC;
+            const bool active = c < dim;
+            const int cc = active ? c : 0;
+            const Vec<VEC> g = Vec<VEC>::load(gout + static_cast<size_t>(r) * dim + cc);
+            Vec<VEC> f[CNT];
+#pragma unroll
+            for (int j = 0; j < CNT; ++j)
+              f[j] = Vec<VEC>::load(ft + (static_cast<size_t>(__builtin_amdgcn_readlane(idx, k0 + j)) * heads + h) * dim + cc);
+            if (active) {
+#pragma unroll
+              for (int j = 0; j < CNT; ++j)
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) part[j] += g.v[t] * f[j].v[t];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < CNT; ++j) part[j] = group_sum<LPR>(part[j]);
+#pragma unroll
+          for (int j = 0; j < CNT; ++j) {
+            dot_sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_l), k0 + j)) * part[j];
+            ga = gl == k0 + j ? part[j] : ga;
+          }
+        });
+        const float g_e = mine ? a_l * (ga - dot_sum) * (pre > 0.0f ? 1.0f : slope) : 0.0f;
+        if (mine) ge[my_pos] = g_e;
+        float ger_acc = 0.0f;
+        for (int k = 0; k < deg; ++k) ger_acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g_e), k));
+        if (gl == 0) ger[r] = ger_acc;
+        continue;
+      }
       // one wave per (node, head): the row's source slices are fetched in chunks of <= 8 so that
       // their loads are in flight together, then the chunk's dot products are reduced with
       // independent butterflies (the wave is convergent: r is wave-uniform)
@@ -240,10 +337,59 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_kernel(
     if (r < 0) continue;
     const int u = r / heads, h = r - u * heads;
     const int beg = t_indptr[u], end = t_indptr[u + 1];
+    const float ger_r = ger != nullptr ? ger[r] : 0.0f;
+    if constexpr (LPR == kWave) {
+      const int deg = end - beg;
+      if (deg <= kWave) {
+        // lane k keeps out-edge k's destination, weight and score gradient (one round of loads for all of them)
+        const bool mine = gl < deg;
+        const int idx = mine ? t_indices[beg + gl] : 0;
+        const size_t my_pos = mine ? static_cast<size_t>(t_pos[beg + gl]) * heads + h : 0;
+        const float a_l = mine ? attn[my_pos] : 0.0f;
+        const float ge_l = mine ? ge[my_pos] : 0.0f;
+        float gel_r = 0.0f;
+        bool have_gel = false;
+        for_columns<VEC, LPR>(dim, [&](int c, bool active) {
+          float acc[VEC];
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) acc[t] = 0.0f;
+          for_chunks<LPR>(0, deg, [&](auto cnt_c, int k0) {
+            constexpr int CNT = decltype(cnt_c)::value;
+            Vec<VEC> val[CNT];
+#pragma unroll
+            for (int j = 0; j < CNT; ++j)
+              val[j] = Vec<VEC>::load(gout + (static_cast<size_t>(__builtin_amdgcn_readlane(idx, k0 + j)) * heads + h) * dim + c);
+            if (!have_gel) {   // in edge order, while the first gradient slices are on their way
+              for (int k = 0; k < deg; ++k)
+                gel_r += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ge_l), k));
+              if (gl == 0) gel[r] = gel_r;
+              have_gel = true;
+            }
+#pragma unroll
+            for (int j = 0; j < CNT; ++j) {
+              const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_l), k0 + j));
+#pragma unroll
+              for (int t = 0; t < VEC; ++t) acc[t] += a * val[j].v[t];
+            }
+          });
+          Vec<VEC> o;
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) o.v[t] = acc[t];
+          if (attn_l != nullptr) {
+            const Vec<VEC> al = Vec<VEC>::load(attn_l + static_cast<size_t>(h) * dim + c);
+            const Vec<VEC> ar = Vec<VEC>::load(attn_r + static_cast<size_t>(h) * dim + c);
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) o.v[t] += gel_r * al.v[t] + ger_r * ar.v[t];
+          }
+          if (active) o.store(gft + static_cast<size_t>(r) * dim + c);
+        });
+        if (!have_gel && gl == 0) gel[r] = 0.0f;   // a node without out-edges
+        continue;
+      }
+    }
     float gel_r = 0.0f;   // every lane of the group adds the same few scalars (no exchange needed)
     for (int k = beg; k < end; ++k) gel_r += ge[static_cast<size_t>(t_pos[k]) * heads + h];
     if (gl == 0) gel[r] = gel_r;
-    const float ger_r = ger != nullptr ? ger[r] : 0.0f;
     for_columns<VEC, LPR>(dim, [&](int c, bool active) {
       float acc[VEC];
 #pragma unroll
