@@ -173,6 +173,34 @@ def test_gat_aggregate_matches_oracle(heads, dim):
         assert torch.allclose(got.grad.cpu(), want.grad, rtol=1e-4, atol=2e-5), name
 
 
+@pytest.mark.parametrize("heads,dim", [(4, 256), (2, 64), (1, 512)])
+def test_gat_aggregate_hubs_and_isolated_sources(heads, dim):
+    """Rows on both sides of the 64-edge limit of the one-lane-per-edge path (dim >= 256: one wave per (node, head)):
+    a node with 100 in-edges, one with 80 out-edges, 9 .. 64 edges (several 8-edge chunks), and a node nobody
+    points at / that points at nobody (the backward's empty out-row)."""
+    n = 220
+    src, dst = random_coo(n, 900, seed=heads + dim, min_in_degree=1)
+    keep = (src != 7) & (dst != 7)                                 # node 7: no in-edge from others, no out-edge
+    src, dst = src[keep], dst[keep]
+    extra_src = np.concatenate([np.arange(20, 120), np.full(80, 3), np.arange(130, 170), [7]])
+    extra_dst = np.concatenate([np.full(100, 5), np.arange(125, 205), np.full(40, 9), [7]])      # 7 -> 7 self-loop only
+    src, dst = np.concatenate([src, extra_src]), np.concatenate([dst, extra_dst])
+    tg, g = ref_and_gts(src, dst, n)
+    assert g.max_in_degree >= 100 and g.min_in_degree >= 1
+    gen = torch.Generator().manual_seed(dim)
+    ft, el, er = torch.randn(n, heads, dim, generator=gen), torch.randn(n, heads, generator=gen), torch.randn(n, heads, generator=gen)
+    gout = torch.randn(n, heads, dim, generator=gen)
+    r = [t.clone().requires_grad_(True) for t in (ft, el, er)]
+    out_ref, _ = torch_ref.gat_aggregate(tg, r[0], r[1], r[2], 0.2)
+    out_ref.backward(gout)
+    d = [t.to(DEV).requires_grad_(True) for t in (ft, el, er)]
+    out = ops.gat_aggregate(g.to(DEV), d[0], d[1], d[2], 0.2)
+    out.backward(gout.to(DEV))
+    assert torch.allclose(out.detach().cpu(), out_ref.detach(), rtol=1e-5, atol=1e-5)
+    for got, want, name in zip(d, r, ("ft", "el", "er")):
+        assert torch.allclose(got.grad.cpu(), want.grad, rtol=1e-4, atol=5e-5), name
+
+
 # ------------------------------------------------------------------ K12
 def test_projection_matches_reference_fixture(golden_dir):
     fx = np.load(os.path.join(golden_dir, "ref_project.npz"))
