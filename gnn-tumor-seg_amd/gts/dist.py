@@ -140,19 +140,21 @@ class FlatGradSync:
         inject theirs through `cross_entropy_sum(logits, labels, class_weights) -> (num, den)`."""
         if cross_entropy_sum is not None:
             num, den = cross_entropy_sum(logits, labels, class_weights)
-        else:
-            from . import ops
-            num, stats = ops.weighted_cross_entropy_stats(logits, labels, class_weights)
-            den = stats[1]
-        num.backward()
-        self._scalars = torch.stack([den.detach(), num.detach()])
+            num.backward()
+            self._scalars = (den.detach().reshape(1), num.detach().reshape(1))
+            return
+        from . import ops
+        grad, stats = ops.weighted_ce_numerator_grad(logits, labels, class_weights)
+        logits.backward(grad)                                   # d(numerator): the kernel's gradient as it is
+        self._scalars = (stats[1:2], stats[0:1])                # (denominator, numerator): views, no launch
 
     def empty_step(self, device=None):
         """This rank has no sample in the (short, last) global batch of the epoch: it contributes
         zero gradients, numerator and denominator, and still takes part in the collective."""
         for p in self.params:
             p.grad = None
-        self._scalars = torch.zeros(2, dtype=torch.float32, device=device or self.params[0].device)
+        zeros = torch.zeros(2, dtype=torch.float32, device=device or self.params[0].device)
+        self._scalars = (zeros[0:1], zeros[1:2])
 
     def all_reduce_and_normalise(self):
         """One concatenation, one collective, one division; afterwards every rank holds the exact
@@ -161,7 +163,7 @@ class FlatGradSync:
         if self._scalars is None:
             raise RuntimeError("call weighted_ce_backward() first")
         pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
-        self.flat = torch.cat(pieces + [self._scalars.to(pieces[0].dtype)])
+        self.flat = torch.cat(pieces + [t.to(pieces[0].dtype) for t in self._scalars])
         self._scalars = None
         _, w = world()
         if w > 1:

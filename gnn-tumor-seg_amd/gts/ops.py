@@ -478,12 +478,21 @@ class _WeightedCE(torch.autograd.Function):
                                       ptr(stats), n, c, current_stream()), "gts_weighted_ce_f32")
         ctx.save_for_backward(grad, stats)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)                 # an unused output arrives as None, not as a zero tensor
         return stats[2].clone(), stats[0].clone(), stats
 
     @staticmethod
     def backward(ctx, g_mean, g_sum, _g_stats):
         grad_unscaled, stats = ctx.saved_tensors
-        scale = g_sum + g_mean / stats[1]                # d(num)/dx = gu ; d(num/den)/dx = gu / den
+        # d(num)/dx = gu ; d(num/den)/dx = gu / den
+        if g_mean is None and g_sum is None:
+            return None, None, None
+        if g_sum is None:
+            scale = g_mean / stats[1]
+        elif g_mean is None:
+            scale = g_sum
+        else:
+            scale = g_sum + g_mean / stats[1]
         return grad_unscaled * scale, None, None
 
 
@@ -496,6 +505,26 @@ def weighted_cross_entropy(logits, labels, class_w=None, reduction="mean"):
     if reduction == "sum":
         return total
     raise ValueError(reduction)
+
+
+def weighted_ce_numerator_grad(logits, labels, class_w=None):
+    """(d numerator / d logits [N, C], [num, den, num/den]) from one launch, outside autograd: what the
+    data-parallel step back-propagates with `logits.backward(grad)` — no clone / fill / scale kernels around
+    the loss (the normalisation by the GLOBAL denominator happens after the all-reduce)."""
+    logits_c, labels = logits.detach().contiguous(), labels.contiguous()
+    _f32(logits_c, class_w)
+    require_device(logits_c, labels, class_w)
+    if logits_c.dim() != 2 or labels.dtype != torch.int64 or labels.shape != logits_c.shape[:1]:
+        raise _lib.GtsError("weighted CE takes logits [N, C] and int64 labels [N]")
+    n, c = logits_c.shape
+    _expect(class_w, (c,), "class_w")
+    lib = _lib.load()
+    ws = torch.empty(max(1, lib.gts_weighted_ce_workspace(n) // 4), dtype=torch.float32, device=logits_c.device)
+    grad = torch.empty_like(logits_c)
+    stats = torch.empty(3, dtype=torch.float32, device=logits_c.device)
+    check(lib.gts_weighted_ce_f32(ptr(logits_c), ptr(labels), ptr(class_w), ptr(grad), ptr(ws), ws.numel() * 4,
+                                  ptr(stats), n, c, current_stream()), "gts_weighted_ce_f32")
+    return grad, stats
 
 
 def weighted_cross_entropy_stats(logits, labels, class_w=None):

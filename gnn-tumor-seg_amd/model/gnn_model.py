@@ -112,11 +112,14 @@ class GNN:
         """One optimizer step on device-resident inputs; returns the loss as a 0-dim tensor."""
         logits = self.net(graph, features)
         if self.grad_sync is None:
-            loss = self.loss_fcn(logits, labels)
+            # loss_fcn(logits, labels).backward() without the autograd node of the loss: the fused pass returns
+            # d(numerator)/d(logits) and [numerator, denominator, mean]; one in-place division makes it the mean's
+            grad, stats = gops.weighted_ce_numerator_grad(logits, labels, self.class_weights)
+            grad.div_(stats[1])
             self.optimizer.zero_grad()
-            loss.backward()
+            logits.backward(grad)
             self.optimizer.step()
-            return loss.detach()
+            return stats[2]
         self.grad_sync.zero_grad()
         self.grad_sync.weighted_ce_backward(logits, labels, self.class_weights)
         loss = self.grad_sync.all_reduce_and_normalise()
@@ -124,7 +127,7 @@ class GNN:
             self.optimizer.step(flat_grad=self.grad_sync.flat_gradients())
         else:
             self.optimizer.step()
-        return loss.clone()
+        return loss                    # a fresh 0-dim tensor (numerator / denominator), nothing aliases it
 
     def empty_step(self):
         """Data-parallel step of a rank without samples (short last global batch): no forward, zero
