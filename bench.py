@@ -79,7 +79,7 @@ def parse_args():
     ap.add_argument("--blocks", type=int, default=10,
                     help="the --steps block is timed this many times; value = the median block")
     ap.add_argument("--graphs-per-gpu", type=int, default=4)
-    ap.add_argument("--graph-kind", default="lattice", choices=["lattice", "random"])
+    ap.add_argument("--graph-kind", default="lattice", choices=["lattice", "random", "selfloop"])
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)

@@ -1657,6 +1657,11 @@ extern "C" int32_t gts_set_option(int32_t option, int32_t value) {
     case GTS_OPT_PROJECT_STREAMING: gts::g_project_nt = value; return GTS_OK;
     case GTS_OPT_WGRAD_TILE: gts::g_wgrad_variant = value; return GTS_OK;
     case GTS_OPT_GEMM_SCHED: gts::g_gemm_sched = value; return GTS_OK;
+    case GTS_OPT_CLUSTER_STREAMING: gts::g_cluster_nt = value; return GTS_OK;
+    case GTS_OPT_CLUSTER_KERNEL: gts::g_cluster_kernel = value; return GTS_OK;
+    case GTS_OPT_CLUSTER_RING: gts::g_cluster_ring = value; return GTS_OK;
+    case GTS_OPT_CLUSTER_PER_CU: gts::g_cluster_per_cu = value; return GTS_OK;
+    case GTS_OPT_CLUSTER_CONSUMERS: gts::g_cluster_consumers = value; return GTS_OK;
     default: return GTS_ERR_ARGKIND;
   }
 }

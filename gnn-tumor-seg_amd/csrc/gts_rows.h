@@ -103,6 +103,11 @@ struct Chunk {
 inline int g_spmm_seq = 0;   // rows per wave; 0 = the kernel's own default
 inline int g_project_nt = 1;  // K12: non-temporal stores of the projected rows
 inline int g_spmm_nt = -1;   // streaming stores/loads of write-once / read-once rows; -1 = default
+inline int g_cluster_nt = -1;  // clustered K1 / K2 (gts_spmm_cluster.hip): bit 0 = streaming stores of out / gx; -1 = default
+inline int g_cluster_kernel = 0;     // 0 = persistent streaming form, 1 = one workgroup per unit, 2 = loader / consumer ring (A/B runs)
+inline int g_cluster_ring = 0;       // form 2: ring slots per workgroup (0 = as many as fit, at most 4)
+inline int g_cluster_per_cu = 0;     // persistent workgroups per CU (0 = automatic)
+inline int g_cluster_consumers = 0;  // form 0: waves per workgroup; form 2: consumer waves (0 = automatic)
 
 inline int pick_seq(int64_t n_rows, int rows_per_wave_step, int preferred) {
   if (g_spmm_seq > 0) return g_spmm_seq;

@@ -1,0 +1,762 @@
+// K1 / K2 at F = 256 over a CLUSTER ROW SCHEDULE: LDS-staged neighbour tiles.
+//
+// The plain kernels (gts_spmm.hip) fetch one 1 KiB source row per edge through the CU's L1 — 5.76 rows per
+// destination on a supervoxel graph, three of four out of the XCD's L2 — behind a chain of dependent index
+// loads (row extent -> edge ids -> rows) that every wave pays for every row.  Measured in the training step at
+// 8 graphs per GPU: 84 / 89 us on the lattice, 59 / 66 us when every row has one neighbour (the same kernels as
+// plain row copies): both the per-edge gather and the dependent chain cost time.
+//
+// Here the rows of the graph are dealt to workgroups as CLUSTERS computed once per graph on the host
+// (gts_cluster_schedule, below): a cluster is a set of <= max_rows rows whose edges touch <= max_srcs distinct
+// neighbour rows (about 2 per row on the 6-neighbour lattice instead of 5.76: the greedy builder finds
+// same-parity rows, which share all their neighbours).  One UNIT of work = one column half (128 floats) of one
+// cluster.  Persistent workgroups (two per CU) walk their units through a double-buffered LDS image:
+//   * at the top of unit t every wave issues ITS share of the gathers of unit t + 1: the 512-byte half of every
+//     distinct neighbour row goes into the other image by LDS-DMA (`buffer_load_dwordx4 ... lds` with per-lane
+//     source addresses: one wave instruction = two row halves, no staging registers), and one more LDS-DMA brings
+//     the index record of unit t + 2 (row ids, per-row edge ranges, one byte per edge = the neighbour's position in
+//     the cluster's list) into a ring of three record slots.  No wave ever waits for an index before it can ask for
+//     a row, and row fetches are in flight while the rows of unit t are reduced;
+//   * then it reduces its rows of unit t out of LDS — half a wave per row, 16 B per lane, edges in CSR slot order,
+//     so results are bit-identical to the plain kernels — and stores 512 B of `out` (+128 B of winners) per row;
+//   * one s_barrier per unit; in front of it a wave waits for its own gathers with a COUNTED vmcnt that leaves the
+//     stores it has just issued in flight (vector-memory operations retire in order: the gathers are older).
+// Units of neighbouring clusters run on one XCD at the same time (halo rows meet in its L2).  The outputs land in
+// the rows the reference's node order gives them; the schedule only decides which workgroup produces which row.
+//
+// Two other forms are kept for A/B runs (GTS_OPT_CLUSTER_KERNEL): 1 = one workgroup per unit (record, barrier,
+// gather, barrier, reduce: 63 / 73 us where the persistent form is measured below); 2 = persistent workgroups
+// with dedicated loader waves feeding a ring of slots to consumer waves (81 - 90 / 108 - 120 us: one wave issuing
+// all gathers of a unit is slow, and the consumers are too few).
+#include <algorithm>
+#include <queue>
+#include <vector>
+
+#include "gts_rows.h"
+
+namespace gts {
+namespace {
+
+constexpr int kF = 256;          // feature width the clustered kernels are built for
+constexpr int kHalfBytes = 512;  // one column half of a row
+constexpr int kArgHalfBytes = 128;
+constexpr unsigned kRsrcFlags = 0x00020000;
+constexpr int kRecRegs = 8;      // a record is at most 64 * kRecRegs words
+constexpr int kMaxRing = 6;
+
+__host__ __device__ inline int pad4(int words) { return (words + 3) & ~3; }
+
+// Word offsets inside one schedule record (all sections padded to 16 bytes):
+//   [0..3] n_rows, n_srcs, n_edges, 0 | row ids | neighbour ids (tail repeats the last) | per row: first 8-edge
+//   chunk (low 16 bits) and degree (high 16 bits) | uint8 per edge: neighbour's position, every row's edges padded
+//   to whole 8-byte chunks (pads repeat the row's last edge) | uint8 per edge: tag, same shape (K2 only)
+struct RecLayout {
+  int rows, srcs, eoff, loc, tag, words;
+};
+__host__ __device__ inline RecLayout rec_layout(int max_rows, int max_srcs, int loc_words, bool tag) {
+  RecLayout r;
+  r.rows = 4;
+  r.srcs = r.rows + pad4(max_rows);
+  r.eoff = r.srcs + pad4(max_srcs);
+  r.loc = r.eoff + pad4(max_rows);
+  r.tag = r.loc + loc_words;
+  r.words = r.tag + (tag ? loc_words : 0);
+  return r;
+}
+
+struct ClusterArgs {
+  const int32_t* rec;      // [n_clusters][layout.words]
+  RecLayout layout;
+  int n_clusters, max_srcs;
+  const float* table;      // K1: x;  K2: gout
+  const uint8_t* winners;  // K2: arg
+  float* out;              // K1: out; K2: gx
+  uint8_t* arg;            // K1: winners out (or null)
+  unsigned table_bytes, winners_bytes;
+  int relu_input, nt;
+  int ring, slot_bytes, image_off, win_off;   // LDS: ring slots of slot_bytes = [record | image | winner image]
+};
+
+__device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// wait until at most n of this wave's vector-memory operations (the youngest) are outstanding
+__device__ __forceinline__ void wait_vm_all_but(int n) {
+  switch (n) {
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // waiting for more is always correct
+  }
+}
+__device__ __forceinline__ void barrier_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- reduce the rows of one unit out of its LDS slot ------------------------------------------------------
+// `first` / `step`: this wave's share of the unit's row pairs (lanes 0-31 one row, lanes 32-63 the next).  Per
+// 8-edge chunk: one 8-byte read gives the chunk's neighbour positions, then CNT 16-byte reads and 3 CNT vector
+// operations per column — straight-line code for the exact count the longer of the wave's two rows needs (CNT is
+// wave-uniform).  The pads of a row's last chunk repeat its last edge: a repeated value never beats the maximum
+// it already is (strict '<'), so the shorter row needs no mask in K1; K2 masks by the degree.
+template <typename Body>
+__device__ __forceinline__ void for_count(int cnt, Body&& body) {
+  switch (cnt) {
+    case 1: body(IC<1>{}); break;
+    case 2: body(IC<2>{}); break;
+    case 3: body(IC<3>{}); break;
+    case 4: body(IC<4>{}); break;
+    case 5: body(IC<5>{}); break;
+    case 6: body(IC<6>{}); break;
+    case 7: body(IC<7>{}); break;
+    default: body(IC<8>{}); break;
+  }
+}
+__device__ __forceinline__ unsigned chunk_byte(const uint2& w, int q) { return ((q < 4 ? w.x : w.y) >> (8 * (q & 3))) & 0xFF; }
+
+template <int ARGB, int WHATIF = 0>   // WHATIF (tools/diag only): 3 = no stores, 4 = stores without the reduction
+__device__ __forceinline__ int reduce_max_rows(const ClusterArgs& a, const int32_t* l_rec, const unsigned char* image,
+                                               int part, int first, int step) {
+  const int lane = threadIdx.x & (kWave - 1), half = lane >> 5, hl = lane & 31;
+  const int n_rows = l_rec[0];
+  const uint32_t* info = reinterpret_cast<const uint32_t*>(l_rec + a.layout.eoff);
+  const uint2* loc = reinterpret_cast<const uint2*>(l_rec + a.layout.loc);
+  const unsigned char* mine = image + hl * 16;
+  int trips = 0;
+  for (int j0 = 2 * first; j0 < n_rows; j0 += 2 * step, ++trips) {   // j0 is wave-uniform: the even row of the pair
+    const int j = j0 + half;
+    const bool have = j < n_rows;
+    const uint32_t ri = have ? info[j] : 0u;
+    const int c0 = ri & 0xFFFF, deg = ri >> 16;
+    const int deg_w = max(__builtin_amdgcn_readlane(deg, 0), __builtin_amdgcn_readlane(deg, 32));
+    float best[4];
+    int slot[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) best[t] = -INFINITY, slot[t] = -1;
+    for (int c = 0; 8 * c < deg_w && WHATIF != 4; ++c) {
+      const bool mine_too = 8 * c < deg;                     // the shorter row of the pair may have run out of chunks
+      const uint2 w = loc[mine_too ? c0 + c : c0];
+      for_count(min(8, deg_w - 8 * c), [&](auto cnt_c) {
+        constexpr int CNT = decltype(cnt_c)::value;
+        float4 val[CNT];
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) val[q] = *reinterpret_cast<const float4*>(mine + chunk_byte(w, q) * kHalfBytes);
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+          const float v4[4] = {val[q].x, val[q].y, val[q].z, val[q].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const bool up = mine_too && best[t] < v4[t];
+            best[t] = up ? v4[t] : best[t];
+            slot[t] = up ? 8 * c + q : slot[t];
+          }
+        }
+      });
+    }
+    Vec<4> o;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool dead = isinf(best[t]);   // same rules as spmm_max_fwd_kernel (gts_spmm.hip)
+      o.v[t] = dead ? 0.0f : best[t];
+      slot[t] = (dead || (a.relu_input && !(best[t] > 0.0f))) ? -1 : slot[t];
+    }
+    if (WHATIF == 3) {
+      if (o.v[0] == 123.456f) a.out[0] = static_cast<float>(slot[0] + slot[1] + slot[2] + slot[3]) + o.v[1] + o.v[2] + o.v[3];
+    } else if (have) {
+      const size_t off = static_cast<size_t>(l_rec[a.layout.rows + j]) * kF + part * (kF / 2) + hl * 4;
+      if (a.nt & 1) o.store_nt(a.out + off); else o.store(a.out + off);
+      if constexpr (ARGB == 1) {
+        const uint32_t w = (slot[0] & 0xFF) | ((slot[1] & 0xFF) << 8) | ((slot[2] & 0xFF) << 16) |
+                           (static_cast<uint32_t>(slot[3] & 0xFF) << 24);
+        *reinterpret_cast<uint32_t*>(a.arg + off) = w;
+      }
+    }
+  }
+  return trips * (ARGB == 1 ? 2 : 1);   // vector-memory instructions this wave has just issued
+}
+
+// K2: rows = sources u; staged = gradient half-rows and winner half-rows of the destinations of their out-edges
+__device__ __forceinline__ int reduce_winner_rows(const ClusterArgs& a, const int32_t* l_rec, const unsigned char* image,
+                                                  const unsigned char* winners, int part, int first, int step) {
+  const int lane = threadIdx.x & (kWave - 1), half = lane >> 5, hl = lane & 31;
+  const int n_rows = l_rec[0];
+  const uint32_t* info = reinterpret_cast<const uint32_t*>(l_rec + a.layout.eoff);
+  const uint2* loc = reinterpret_cast<const uint2*>(l_rec + a.layout.loc);
+  const uint2* tag = reinterpret_cast<const uint2*>(l_rec + a.layout.tag);
+  const unsigned char* my_g = image + hl * 16;
+  const unsigned char* my_w = winners + hl * 4;
+  int trips = 0;
+  for (int j0 = 2 * first; j0 < n_rows; j0 += 2 * step, ++trips) {
+    const int j = j0 + half;
+    const bool have = j < n_rows;
+    const uint32_t ri = have ? info[j] : 0u;
+    const int c0 = ri & 0xFFFF, deg = ri >> 16;
+    const int deg_w = max(__builtin_amdgcn_readlane(deg, 0), __builtin_amdgcn_readlane(deg, 32));
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; 8 * c < deg_w; ++c) {
+      const int at = 8 * c < deg ? c0 + c : c0;
+      const uint2 w = loc[at], tg = tag[at];
+      for_count(min(8, deg_w - 8 * c), [&](auto cnt_c) {
+        constexpr int CNT = decltype(cnt_c)::value;
+        float4 g[CNT];
+        uint32_t win[CNT];
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+          const unsigned s = chunk_byte(w, q);
+          g[q] = *reinterpret_cast<const float4*>(my_g + s * kHalfBytes);
+          win[q] = *reinterpret_cast<const uint32_t*>(my_w + s * kArgHalfBytes);
+        }
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+          const unsigned want = chunk_byte(tg, q);
+          const bool live = 8 * c + q < deg;
+          const float g4[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] += (live && ((win[q] >> (8 * t)) & 0xFF) == want) ? g4[t] : 0.0f;
+        }
+      });
+    }
+    if (have) {
+      const size_t off = static_cast<size_t>(l_rec[a.layout.rows + j]) * kF + part * (kF / 2) + hl * 4;
+      const Vec<4> o{{acc[0], acc[1], acc[2], acc[3]}};
+      if (a.nt & 1) o.store_nt(a.out + off); else o.store(a.out + off);
+    }
+  }
+  return trips;
+}
+
+// ---- gathers (LDS-DMA) ---------------------------------------------------------------------------------------
+// Two ways to issue `buffer_load_dwordx4 ... lds` (64 lanes x 16 B from per-lane byte offsets into one contiguous
+// KiB of LDS):
+//   * BuiltinDma: the clang builtin.  hipcc's wait-count pass then treats the transfer as a pending LDS write and
+//     puts `s_waitcnt vmcnt(0)` in front of every later LDS read it cannot tell apart from it — right for the forms
+//     that gather, wait, and only then read;
+//   * RawDma: the same instruction as inline assembly, for the streaming form, which reads one image while the
+//     gathers into the OTHER image are in flight and orders the two itself (counted vmcnt + workgroup barrier).
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned char* LdsBytes;
+
+struct BuiltinDma {
+  __amdgpu_buffer_rsrc_t rsrc;
+  __device__ __forceinline__ BuiltinDma(const void* base, unsigned bytes)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcFlags)) {}
+  __device__ __forceinline__ void operator()(unsigned char* lds_dst, unsigned voff) const {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, reinterpret_cast<float*>(lds_dst), 16, voff, 0, 0, 0);
+  }
+};
+struct RawDma {
+  v4i rsrc;   // buffer resource words: base[31:0] | base[47:32] (stride 0) | bytes | flags
+  __device__ __forceinline__ RawDma(const void* base, unsigned bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    rsrc = v4i{static_cast<int>(b), static_cast<int>((b >> 32) & 0xFFFF), static_cast<int>(bytes), static_cast<int>(kRsrcFlags)};
+  }
+  __device__ __forceinline__ void operator()(unsigned char* lds_dst, unsigned voff) const {
+    const unsigned at = static_cast<unsigned>(reinterpret_cast<uintptr_t>((LdsBytes)lds_dst));   // wave-uniform
+    unsigned keep;   // M0 holds the LDS destination; it is handed back as found
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(at), "v"(voff), "s"(rsrc) : "memory");
+  }
+};
+
+// One column half of n_srcs neighbour rows -> image [n_srcs][512 B].  `src_of(i)` gives this lane's neighbour id
+// for the pair of rows (i, i + 1): lanes 0-31 fetch row i, lanes 32-63 row i + 1 (the record repeats the last id
+// after the end, and the host reserves an even number of image rows).  `first`, `step` in rows (even).
+template <typename Dma, typename SrcOf>
+__device__ __forceinline__ void gather_halves(const Dma& dma, int part, unsigned char* image, int n_srcs,
+                                              int first, int step, SrcOf&& src_of) {
+  const int hl = threadIdx.x & 31;
+  for (int i = first; i < n_srcs; i += step) {
+    const unsigned voff = static_cast<unsigned>(src_of(i)) * (kF * 4u) + static_cast<unsigned>(part) * kHalfBytes + hl * 16u;
+    dma(image + i * kHalfBytes, voff);
+  }
+}
+// winner halves (128 B per row): 8 lanes x 16 B per row, eight rows per wave instruction
+template <typename Dma, typename SrcOf>
+__device__ __forceinline__ void gather_winner_halves(const Dma& dma, int part, unsigned char* image,
+                                                     int n_srcs, int first, int step, SrcOf&& src_of) {
+  const int l8 = threadIdx.x & 7;
+  for (int i = first; i < n_srcs; i += step) {
+    const unsigned voff = static_cast<unsigned>(src_of(i)) * static_cast<unsigned>(kF) +
+                          static_cast<unsigned>(part) * kArgHalfBytes + l8 * 16u;
+    dma(image + i * kArgHalfBytes, voff);
+  }
+}
+
+// ---- the persistent streaming kernel --------------------------------------------------------------------------
+// gridDim.x is a multiple of 8: the workgroups with blockIdx % 8 == x (one XCD under round-robin placement; speed
+// only) share the x-th eighth of the units and take them round-robin.  LDS: three record slots, two images.
+// WHATIF != 0 only in the timing experiments of tools/diag (wrong results): 1 = no row gathers, 2 = no reduction and
+// no stores, 3 = no stores, 4 = stores without the reduction (K1).
+template <bool BWD, int ARGB, int WHATIF = 0>
+__global__ __launch_bounds__(512) void spmm_cluster_stream_kernel(const ClusterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int n_waves = blockDim.x / kWave;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const long long n_units = 2LL * a.n_clusters;
+  const int lo = static_cast<int>(n_units * xcd / 8), hi = static_cast<int>(n_units * (xcd + 1) / 8);
+  const int n_my = lo + j < hi ? (hi - lo - j + per_xcd - 1) / per_xcd : 0;   // units lo + j + t * per_xcd, t < n_my
+  if (n_my == 0) return;
+  const int words = a.layout.words;
+  const int pieces = (words + 255) / 256;   // a record arrives as one or two whole 1 KiB LDS-DMA pieces (lanes past its end deliver zeros)
+  const int rec_bytes = 1024 * pieces, image_bytes = a.slot_bytes - a.image_off;
+  unsigned char* images = lds + 3 * rec_bytes;
+  const RawDma rr(a.rec, static_cast<unsigned>(a.n_clusters) * words * 4u);
+  const RawDma rt(a.table, a.table_bytes);
+  const RawDma rw(a.winners, BWD ? a.winners_bytes : 0);
+  auto fetch_record = [&](int t) {          // record of unit t -> its slot, by LDS-DMA (waves 0 / 1: one piece each)
+    if (wave < pieces) {
+      const unsigned cluster = static_cast<unsigned>(lo + j + t * per_xcd) >> 1;
+      const int word = 256 * wave + 4 * lane;
+      const unsigned voff = word < words ? (cluster * static_cast<unsigned>(words) + word) * 4u : 0xFFFFFFF0u;
+      rr(lds + (t % 3) * rec_bytes + 1024 * wave, voff);
+    }
+  };
+  auto issue_gathers = [&](int t) {         // this wave's share of unit t's gathers; its record is in LDS
+    const int32_t* l_rec = reinterpret_cast<const int32_t*>(lds + (t % 3) * rec_bytes);
+    unsigned char* image = images + (t & 1) * image_bytes;
+    const int n_srcs = l_rec[1];
+    const int part = (lo + j + t * per_xcd) & 1;
+    const int half = lane >> 5;
+    // lane l keeps the id of row 2 (wave + n_waves (l / 2)) + l % 2: every row pair this wave fetches, one LDS read
+    const int last = pad4(a.max_srcs) - 1;
+    const int32_t ids = l_rec[a.layout.srcs + min(2 * (wave + n_waves * (lane >> 1)) + (lane & 1), last)];
+    int k = 0;
+    gather_halves(rt, part, image, n_srcs, 2 * wave, 2 * n_waves, [&](int) {
+      const int s0 = __builtin_amdgcn_readlane(ids, 2 * k), s1 = __builtin_amdgcn_readlane(ids, 2 * k + 1);
+      ++k;
+      return half ? s1 : s0;
+    });
+    if constexpr (BWD) {
+      // lane l keeps the id of row 8 (wave + n_waves (l / 8)) + l % 8; piece k wants lanes 8 k .. 8 k + 7 spread by eights
+      const int32_t ids8 = l_rec[a.layout.srcs + min(8 * (wave + n_waves * (lane >> 3)) + (lane & 7), last)];
+      int k8 = 0;
+      gather_winner_halves(rw, part, image + ((a.max_srcs + 1) & ~1) * kHalfBytes, n_srcs, 8 * wave, 8 * n_waves, [&](int) {
+        const int32_t id = __builtin_amdgcn_ds_bpermute(4 * (8 * k8 + (lane >> 3)), ids8);
+        ++k8;
+        return id;
+      });
+    }
+  };
+
+  fetch_record(0);
+  if (1 < n_my) fetch_record(1);
+  barrier_all();
+  issue_gathers(0);
+  int stores = 0;                           // stores this wave issued after its last gathers
+  for (int it = 0; it < n_my; ++it) {
+    wait_vm_all_but(stores);                // my gathers of unit `it` (and the record I fetched) have landed
+    barrier_lds();                          // ... and everyone else's; the other image and the oldest record slot are free
+    if (it + 1 < n_my && WHATIF != 1) issue_gathers(it + 1);
+    if (it + 2 < n_my) fetch_record(it + 2);
+    const int32_t* l_rec = reinterpret_cast<const int32_t*>(lds + (it % 3) * rec_bytes);
+    const unsigned char* image = images + (it & 1) * image_bytes;
+    const int part = (lo + j + it * per_xcd) & 1;
+    if constexpr (WHATIF == 2)
+      stores = 0;
+    else if constexpr (WHATIF >= 3 && !BWD)
+      stores = WHATIF == 3 ? (reduce_max_rows<ARGB, WHATIF>(a, l_rec, image, part, wave, n_waves), 0)
+                           : reduce_max_rows<ARGB, WHATIF>(a, l_rec, image, part, wave, n_waves);
+    else if constexpr (BWD)
+      stores = reduce_winner_rows(a, l_rec, image, image + ((a.max_srcs + 1) & ~1) * kHalfBytes, part, wave, n_waves);
+    else
+      stores = reduce_max_rows<ARGB>(a, l_rec, image, part, wave, n_waves);
+  }
+}
+
+// ---- the persistent ring kernel -------------------------------------------------------------------------------
+// blockDim = 64 * (ring - 1 + consumers).  gridDim.x is a multiple of 8: the workgroups with blockIdx % 8 == x
+// (one XCD under round-robin placement; speed only) share the x-th eighth of the units and take them round-robin.
+template <bool BWD, int ARGB>
+__global__ __launch_bounds__(512) void spmm_cluster_ring_kernel(const ClusterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int n_waves = blockDim.x / kWave;
+  const int n_loaders = a.ring - 1, n_consumers = n_waves - n_loaders;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const long long n_units = 2LL * a.n_clusters;
+  const int lo = static_cast<int>(n_units * xcd / 8), hi = static_cast<int>(n_units * (xcd + 1) / 8);
+  const int n_my = lo + j < hi ? (hi - lo - j + per_xcd - 1) / per_xcd : 0;   // units lo + j + t * per_xcd, t < n_my
+  const int words = a.layout.words;
+
+  if (wave < n_loaders) {
+    // ------------------------------------------------------------------ loader: units t = wave, wave + n_loaders, ...
+    const BuiltinDma rt(a.table, a.table_bytes);
+    const BuiltinDma rw(a.winners, BWD ? a.winners_bytes : 0);
+    int32_t regs[kRecRegs];
+    int32_t src_a = 0, src_b = 0, src_c = 0, src_d = 0;   // neighbour ids 0-63 / 64-127 / 128-191 / 192-255, lane = id index % 64
+    auto fetch = [&](int t) {         // record of unit t -> registers (global loads, not waited for here)
+      const int32_t* r = a.rec + static_cast<size_t>((lo + j + t * per_xcd) >> 1) * words;
+#pragma unroll
+      for (int q = 0; q < kRecRegs; ++q) regs[q] = lane + 64 * q < words ? r[lane + 64 * q] : 0;
+      const int32_t* s = r + a.layout.srcs;
+      src_a = lane < a.max_srcs ? s[lane] : 0;
+      src_b = lane + 64 < a.max_srcs ? s[lane + 64] : 0;
+      src_c = lane + 128 < a.max_srcs ? s[lane + 128] : 0;
+      src_d = lane + 192 < a.max_srcs ? s[lane + 192] : 0;
+    };
+    auto issue = [&](int t) {         // registers -> the unit's slot, then its gathers
+      unsigned char* slot = lds + (t % a.ring) * a.slot_bytes;
+      int32_t* l_rec = reinterpret_cast<int32_t*>(slot);
+#pragma unroll
+      for (int q = 0; q < kRecRegs; ++q)
+        if (lane + 64 * q < words) l_rec[lane + 64 * q] = regs[q];
+      const int n_srcs = __builtin_amdgcn_readlane(regs[0], 1);
+      const int part = (lo + j + t * per_xcd) & 1;
+      const int half = lane >> 5;
+      gather_halves(rt, part, slot + a.image_off, n_srcs, 0, 2, [&](int i) {
+        const int32_t r = i < 64 ? src_a : i < 128 ? src_b : i < 192 ? src_c : src_d;   // i is wave-uniform and even
+        const int s0 = __builtin_amdgcn_readlane(r, i & 63), s1 = __builtin_amdgcn_readlane(r, (i & 63) + 1);
+        return half ? s1 : s0;
+      });
+      if constexpr (BWD) {
+        const int sub = lane >> 3;
+        gather_winner_halves(rw, part, slot + a.win_off, n_srcs, 0, 8, [&](int i) {
+          const int32_t r = i < 64 ? src_a : i < 128 ? src_b : i < 192 ? src_c : src_d;
+          // lane group g (8 lanes) wants id i + g: a cross-lane read of lane (i & 63) + g
+          return __builtin_amdgcn_ds_bpermute(4 * ((i & 63) + sub), r);
+        });
+      }
+    };
+    if (wave < n_my) {
+      fetch(wave);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      issue(wave);
+      if (wave + n_loaders < n_my) fetch(wave + n_loaders);
+    }
+    for (int it = 0; it < n_my; ++it) {
+      if (it % n_loaders == wave) {
+        barrier_all();                          // my gather of unit `it` has landed (and my next record has arrived)
+        const int t = it + n_loaders;           // the slot unit it - 1 used is free now
+        if (t < n_my) {
+          issue(t);
+          if (t + n_loaders < n_my) fetch(t + n_loaders);
+        }
+      } else {
+        barrier_lds();
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ consumer
+    const int me = wave - n_loaders;
+    for (int it = 0; it < n_my; ++it) {
+      barrier_lds();                            // unit `it` is complete in its slot
+      const unsigned char* slot = lds + (it % a.ring) * a.slot_bytes;
+      const int part = (lo + j + it * per_xcd) & 1;
+      if constexpr (BWD)
+        reduce_winner_rows(a, reinterpret_cast<const int32_t*>(slot), slot + a.image_off, slot + a.win_off, part, me, n_consumers);
+      else
+        reduce_max_rows<ARGB>(a, reinterpret_cast<const int32_t*>(slot), slot + a.image_off, part, me, n_consumers);
+    }
+  }
+}
+
+// ---- the simple form: one workgroup of 256 threads per unit ---------------------------------------------------
+template <bool BWD, int ARGB>
+__global__ __launch_bounds__(kBlock) void spmm_cluster_unit_kernel(const ClusterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int u = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+  const int part = u & 1;
+  const int32_t* r = a.rec + static_cast<size_t>(u >> 1) * a.layout.words;
+  int32_t* l_rec = reinterpret_cast<int32_t*>(lds);
+  for (int i = threadIdx.x; i < a.layout.words; i += kBlock) l_rec[i] = r[i];
+  __syncthreads();
+  const int n_srcs = l_rec[1];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int32_t* l_srcs = l_rec + a.layout.srcs;
+  const BuiltinDma rt(a.table, a.table_bytes);
+  gather_halves(rt, part, lds + a.image_off, n_srcs, 2 * wave, 2 * kWavesPerBlock, [&](int i) { return l_srcs[i + (lane >> 5)]; });
+  if constexpr (BWD) {
+    const BuiltinDma rw(a.winners, a.winners_bytes);
+    gather_winner_halves(rw, part, lds + a.win_off, n_srcs, 8 * wave, 8 * kWavesPerBlock,
+                         [&](int i) { return l_srcs[min(i + (lane >> 3), n_srcs - 1)]; });
+  }
+  __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+  if constexpr (BWD)
+    reduce_winner_rows(a, l_rec, lds + a.image_off, lds + a.win_off, part, wave, kWavesPerBlock);
+  else
+    reduce_max_rows<ARGB>(a, l_rec, lds + a.image_off, part, wave, kWavesPerBlock);
+}
+
+constexpr int64_t kMaxLds = 160 * 1024;
+
+struct LdsPlan {
+  int slot_bytes, image_off, win_off;
+};
+inline LdsPlan lds_plan(int max_rows, int max_srcs, int loc_words, bool bwd) {
+  const RecLayout l = rec_layout(max_rows, max_srcs, loc_words, bwd);
+  LdsPlan p;
+  p.image_off = (l.words * 4 + 15) & ~15;
+  const int image = ((max_srcs + 1) & ~1) * kHalfBytes;
+  p.win_off = p.image_off + image;
+  p.slot_bytes = p.win_off + (bwd ? ((max_srcs + 7) & ~7) * kArgHalfBytes : 0);
+  return p;
+}
+
+inline int device_cus() {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  return cus;
+}
+
+template <typename Kernel>
+inline void allow_big_lds(Kernel k) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMaxLds));
+}
+
+template <bool BWD, int ARGB, int WHATIF = 0>
+inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_t st) {
+  const LdsPlan p = lds_plan(max_rows, a.max_srcs, loc_words, BWD);
+  a.image_off = p.image_off, a.win_off = p.win_off, a.slot_bytes = p.slot_bytes;
+  if (p.slot_bytes > kMaxLds) return GTS_ERR_SHAPE;
+  if (g_cluster_kernel == 1) {
+    static const bool once = (allow_big_lds(spmm_cluster_unit_kernel<BWD, ARGB>), true);
+    (void)once;
+    spmm_cluster_unit_kernel<BWD, ARGB><<<dim3(static_cast<unsigned>(2 * a.n_clusters)), kBlock, p.slot_bytes, st>>>(a);
+    return launch_status();
+  }
+  const int64_t units = 2LL * a.n_clusters;
+  if (g_cluster_kernel != 2) {
+    // persistent streaming form: three record slots + two images per workgroup, as many workgroups per CU as fit (<= 2)
+    const int64_t wg_lds = 3LL * 1024 * ((a.layout.words + 255) / 256) + 2LL * (p.slot_bytes - p.image_off);
+    if (wg_lds > kMaxLds || a.layout.words > 512) return GTS_ERR_SHAPE;
+    const int waves = g_cluster_consumers > 0 ? std::min(8, g_cluster_consumers) : 8;
+    if (a.max_srcs > 64 * waves) return GTS_ERR_SHAPE;
+    const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g_cluster_per_cu > 0 ? g_cluster_per_cu : 2, kMaxLds / wg_lds)));
+    int64_t grid = static_cast<int64_t>(device_cus()) * per_cu;
+    grid = std::max<int64_t>(8, std::min(grid, (units + 7) / 8 * 8)) / 8 * 8;
+    static const bool once = (allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF>), true);
+    (void)once;
+    spmm_cluster_stream_kernel<BWD, ARGB, WHATIF><<<dim3(static_cast<unsigned>(grid)), waves * kWave, wg_lds, st>>>(a);
+    return launch_status();
+  }
+  // loader / consumer ring: as many slots as fit (at least 2: one loader), at most kMaxRing
+  int ring = g_cluster_ring > 0 ? g_cluster_ring : static_cast<int>(std::min<int64_t>(4, kMaxLds / p.slot_bytes));
+  ring = std::max(2, std::min(ring, kMaxRing));
+  if (static_cast<int64_t>(ring) * p.slot_bytes > kMaxLds) ring = static_cast<int>(kMaxLds / p.slot_bytes);
+  if (ring < 2) return GTS_ERR_SHAPE;
+  const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g_cluster_per_cu > 0 ? g_cluster_per_cu : 1,
+                                                                               kMaxLds / (static_cast<int64_t>(ring) * p.slot_bytes))));
+  a.ring = ring;
+  const int consumers = g_cluster_consumers > 0 ? g_cluster_consumers : 8 - (ring - 1);
+  const int waves = std::min(8, ring - 1 + std::max(1, consumers));
+  int64_t grid = static_cast<int64_t>(device_cus()) * per_cu;
+  grid = std::max<int64_t>(8, std::min(grid, (units + 7) / 8 * 8)) / 8 * 8;
+  static const bool once = (allow_big_lds(spmm_cluster_ring_kernel<BWD, ARGB>), true);
+  (void)once;
+  spmm_cluster_ring_kernel<BWD, ARGB><<<dim3(static_cast<unsigned>(grid)), waves * kWave, ring * p.slot_bytes, st>>>(a);
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace gts
+
+// ---------------------------------------------------------------------------------------------------------
+// Host: the greedy cluster builder.  Plain C++, no GPU call.
+extern "C" int64_t gts_cluster_record_words(int32_t max_rows, int32_t max_srcs, int32_t loc_words, int32_t with_tag) {
+  if (max_rows < 1 || max_srcs < 1 || loc_words < 0 || loc_words % 4 != 0) return -1;
+  return gts::rec_layout(max_rows, max_srcs, loc_words, with_tag != 0).words;
+}
+
+extern "C" int32_t gts_cluster_schedule(const int32_t* indptr, const int32_t* indices, const int32_t* t_indptr,
+                                        const int32_t* t_indices, const int32_t* edge_tag, int64_t n_rows,
+                                        int32_t max_rows, int32_t max_srcs, int32_t max_edges, int32_t* rec,
+                                        int64_t rec_capacity, int64_t* n_clusters, int64_t* n_staged,
+                                        int32_t* max_cluster_edges) {
+  using namespace gts;
+  if (!indptr || !t_indptr || !n_clusters || !n_staged || !max_cluster_edges) return GTS_ERR_NULL;
+  if (n_rows < 0 || n_rows >= (1LL << 31)) return GTS_ERR_SHAPE;
+  if (max_rows < 1 || max_srcs < 1 || max_srcs > 256 || max_edges < 1 || max_edges > 65535) return GTS_ERR_ARGKIND;
+  const int n = static_cast<int>(n_rows);
+  if (n > 0 && (!indices || !t_indices) && indptr[n] > 0) return GTS_ERR_NULL;
+  for (int v = 0; v < n; ++v) {   // every row must fit a cluster of its own
+    const int deg = indptr[v + 1] - indptr[v];
+    if (deg > max_srcs || ((deg + 7) & ~7) > max_edges || deg > 65535) return GTS_ERR_SHAPE;
+  }
+  if (edge_tag != nullptr) {
+    const int e = n > 0 ? indptr[n] : 0;
+    for (int k = 0; k < e; ++k)
+      if (edge_tag[k] < 0 || edge_tag[k] > 255) return GTS_ERR_SHAPE;
+  }
+  const int loc_words = pad4((max_edges + 3) / 4);   // max_edges counts PADDED edges: every row takes whole 8-edge chunks
+  const RecLayout L = rec_layout(max_rows, max_srcs, loc_words, edge_tag != nullptr);
+  if (L.words > 64 * kRecRegs) return GTS_ERR_ARGKIND;
+  std::vector<uint8_t> assigned(n, 0);
+  std::vector<int> gain(n, 0), stamp(n, -1);      // gain[w] valid when stamp[w] == current cluster
+  std::vector<int> local(n, -1), lstamp(n, -1);   // neighbour id -> position in this cluster's list (valid by lstamp)
+  using Cand = std::pair<int, int>;                // (gain, -row): most shared neighbours first, then lowest id
+  std::priority_queue<Cand> heap;
+  std::priority_queue<int, std::vector<int>, std::greater<int>> seeds;   // rows that touch finished clusters
+  std::vector<int> rows, srcs, touched;
+  int next_unassigned = 0, most_edges = 0;
+  int64_t n_cl = 0, staged = 0;
+  while (true) {
+    int seed = -1;
+    while (!seeds.empty()) {
+      const int s = seeds.top();
+      seeds.pop();
+      if (!assigned[s]) { seed = s; break; }
+    }
+    if (seed < 0) {
+      while (next_unassigned < n && assigned[next_unassigned]) ++next_unassigned;
+      if (next_unassigned == n) break;
+      seed = next_unassigned;
+    }
+    const int cl = static_cast<int>(n_cl);
+    rows.clear(), srcs.clear(), touched.clear();
+    int n_e = 0;
+    while (!heap.empty()) heap.pop();
+    heap.push({0, -seed});
+    stamp[seed] = cl, gain[seed] = 0;
+    bool full = false, misfit = false;
+    while (!full) {
+      if (heap.empty()) {
+        if (misfit) break;   // candidates were left out for lack of room: the cluster is as full as it gets
+        // the component is exhausted: go on with the next unassigned row, so that small components and
+        // isolated rows share clusters
+        while (next_unassigned < n && assigned[next_unassigned]) ++next_unassigned;
+        if (next_unassigned == n) break;
+        const int s = next_unassigned;
+        if (stamp[s] != cl) stamp[s] = cl, gain[s] = 0;
+        heap.push({gain[s], -s});
+      }
+      const Cand top = heap.top();
+      heap.pop();
+      const int v = -top.second;
+      if (assigned[v] || stamp[v] != cl || gain[v] != top.first) continue;   // stale entry
+      const int beg = indptr[v], end = indptr[v + 1];
+      int fresh = 0;
+      for (int k = beg; k < end; ++k) {
+        const int u = indices[k];
+        if (lstamp[u] != cl) lstamp[u] = cl, local[u] = -1;
+        if (local[u] == -1) local[u] = -2, ++fresh;          // -2: counted as new for this row
+      }
+      const int padded = (end - beg + 7) & ~7;
+      const bool fits = static_cast<int>(rows.size()) < max_rows &&
+                        static_cast<int>(srcs.size()) + fresh <= max_srcs && n_e + padded <= max_edges;
+      if (!fits) {
+        for (int k = beg; k < end; ++k)
+          if (local[indices[k]] == -2) local[indices[k]] = -1;
+        if (rows.empty()) return GTS_ERR_SHAPE;   // cannot happen after the degree check
+        misfit = true;
+        continue;                                  // another candidate may still fit
+      }
+      assigned[v] = 1;
+      rows.push_back(v);
+      n_e += padded;
+      for (int k = beg; k < end; ++k) {
+        const int u = indices[k];
+        if (local[u] != -2) continue;
+        local[u] = static_cast<int>(srcs.size());
+        srcs.push_back(u);
+        for (int q = t_indptr[u]; q < t_indptr[u + 1]; ++q) {   // every row that lists u shares it now
+          const int w = t_indices[q];
+          if (assigned[w]) continue;
+          if (stamp[w] != cl) stamp[w] = cl, gain[w] = 0, touched.push_back(w);
+          ++gain[w];
+          heap.push({gain[w], -w});
+        }
+      }
+      if (static_cast<int>(rows.size()) >= max_rows) full = true;
+    }
+    for (int w : touched)
+      if (!assigned[w]) seeds.push(w);
+    most_edges = std::max(most_edges, n_e);
+    staged += static_cast<int64_t>(srcs.size());
+    if (rec != nullptr && n_cl < rec_capacity) {
+      // the record: rows in ascending id (neighbouring output rows leave together), edges in CSR slot order
+      std::sort(rows.begin(), rows.end());
+      int32_t* r = rec + n_cl * L.words;
+      std::fill(r, r + L.words, 0);
+      r[0] = static_cast<int32_t>(rows.size()), r[1] = static_cast<int32_t>(srcs.size()), r[2] = n_e;
+      uint8_t* loc = reinterpret_cast<uint8_t*>(r + L.loc);
+      uint8_t* tag = reinterpret_cast<uint8_t*>(r + L.tag);
+      int e_at = 0;   // padded edge position: a multiple of 8 at every row start
+      for (size_t i = 0; i < rows.size(); ++i) {
+        const int v = rows[i], deg = indptr[v + 1] - indptr[v];
+        r[L.rows + i] = v;
+        r[L.eoff + i] = static_cast<int32_t>(static_cast<uint32_t>(e_at / 8) | (static_cast<uint32_t>(deg) << 16));
+        for (int k = indptr[v]; k < indptr[v + 1]; ++k, ++e_at) {
+          loc[e_at] = static_cast<uint8_t>(local[indices[k]]);
+          if (edge_tag != nullptr) tag[e_at] = static_cast<uint8_t>(edge_tag[k]);
+        }
+        for (; e_at % 8 != 0; ++e_at) {   // pads repeat the row's last edge
+          loc[e_at] = loc[e_at - 1];
+          if (edge_tag != nullptr) tag[e_at] = tag[e_at - 1];
+        }
+      }
+      for (int i = 0; i < pad4(max_srcs); ++i)   // the tail repeats the last id: gathers run in whole pairs / octets
+        r[L.srcs + i] = srcs.empty() ? 0 : srcs[std::min<size_t>(i, srcs.size() - 1)];
+    }
+    ++n_cl;
+  }
+  *n_clusters = n_cl;
+  *n_staged = staged;
+  *max_cluster_edges = most_edges;
+  return GTS_OK;
+}
+
+// LDS bytes of one ring slot (= of one workgroup of the simple form) for a schedule with these limits
+// (kind 0 = K1 forward, 1 = K2 backward).
+extern "C" int64_t gts_cluster_lds_bytes(int32_t max_rows, int32_t max_srcs, int32_t loc_words, int32_t kind) {
+  if (max_rows < 1 || max_srcs < 1 || loc_words < 0 || loc_words % 4 != 0 || (kind != 0 && kind != 1)) return -1;
+  return gts::lds_plan(max_rows, max_srcs, loc_words, kind == 1).slot_bytes;
+}
+
+namespace {
+inline bool bad_cluster_shape(int64_t n_clusters, int32_t max_rows, int32_t max_srcs, int32_t loc_words, bool tag,
+                              int64_t n_rows, int64_t n_feat) {
+  if (n_feat != gts::kF || n_rows < 0 || n_rows * gts::kF * 4 >= (1LL << 32) || n_clusters < 0 || n_clusters >= (1 << 30))
+    return true;
+  if (max_rows < 1 || max_srcs < 1 || max_srcs > 256 || loc_words < 0 || loc_words % 4 != 0 || loc_words > 16384) return true;
+  return gts::rec_layout(max_rows, max_srcs, loc_words, tag).words > 64 * gts::kRecRegs;
+}
+}  // namespace
+
+extern "C" int32_t gts_spmm_max_fwd_cluster_f32(const int32_t* rec, int64_t n_clusters, int32_t max_rows, int32_t max_srcs,
+                                                int32_t loc_words, const float* x, float* out, void* arg,
+                                                int32_t arg_bytes, int32_t relu_input, int64_t n_rows, int64_t n_feat,
+                                                void* stream) {
+  using namespace gts;
+  if (!rec || !x || !out || (arg_bytes != 0 && !arg)) return GTS_ERR_NULL;
+  if (bad_cluster_shape(n_clusters, max_rows, max_srcs, loc_words, false, n_rows, n_feat)) return GTS_ERR_SHAPE;
+  if (arg_bytes != 0 && arg_bytes != 1) return GTS_ERR_ARGKIND;
+  if (n_clusters == 0) return GTS_OK;
+  ClusterArgs a{};
+  a.rec = rec, a.layout = rec_layout(max_rows, max_srcs, loc_words, false);
+  a.n_clusters = static_cast<int>(n_clusters), a.max_srcs = max_srcs;
+  a.table = x, a.out = out, a.arg = static_cast<uint8_t*>(arg);
+  a.table_bytes = static_cast<unsigned>(n_rows * kF * 4);
+  a.relu_input = relu_input, a.nt = g_cluster_nt < 0 ? 1 : g_cluster_nt;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return arg_bytes == 0 ? launch_cluster<false, 0>(a, max_rows, loc_words, st) : launch_cluster<false, 1>(a, max_rows, loc_words, st);
+}
+
+extern "C" int32_t gts_spmm_max_bwd_cluster_f32(const int32_t* rec, int64_t n_clusters, int32_t max_rows, int32_t max_srcs,
+                                                int32_t loc_words, const float* gout, const void* arg, int32_t arg_bytes,
+                                                float* gx, int64_t n_rows, int64_t n_feat, void* stream) {
+  using namespace gts;
+  if (!rec || !gout || !arg || !gx) return GTS_ERR_NULL;
+  if (bad_cluster_shape(n_clusters, max_rows, max_srcs, loc_words, true, n_rows, n_feat)) return GTS_ERR_SHAPE;
+  if (arg_bytes != 1) return GTS_ERR_ARGKIND;
+  if (n_clusters == 0) return GTS_OK;
+  ClusterArgs a{};
+  a.rec = rec, a.layout = rec_layout(max_rows, max_srcs, loc_words, true);
+  a.n_clusters = static_cast<int>(n_clusters), a.max_srcs = max_srcs;
+  a.table = gout, a.winners = static_cast<const uint8_t*>(arg), a.out = gx;
+  a.table_bytes = static_cast<unsigned>(n_rows * kF * 4), a.winners_bytes = static_cast<unsigned>(n_rows * kF);
+  a.nt = g_cluster_nt < 0 ? 1 : g_cluster_nt;
+  return launch_cluster<true, 1>(a, max_rows, loc_words, static_cast<hipStream_t>(stream));
+}

@@ -10,7 +10,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgts_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "gts_hip.h")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -24,6 +24,11 @@ SIGNATURES = {
     "gts_error_string": [_i32],
     "gts_spmm_max_fwd_f32": [_p, _p, _p, _p, _p, _i32, _i32, _i64, _i64, _p],
     "gts_spmm_max_bwd_f32": [_p, _p, _p, _p, _p, _i32, _p, _p, _i64, _i64, _p],
+    "gts_cluster_record_words": [_i32, _i32, _i32, _i32],
+    "gts_cluster_schedule": [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p],
+    "gts_cluster_lds_bytes": [_i32, _i32, _i32, _i32],
+    "gts_spmm_max_fwd_cluster_f32": [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _i32, _i64, _i64, _p],
+    "gts_spmm_max_bwd_cluster_f32": [_p, _i64, _i32, _i32, _i32, _p, _p, _i32, _p, _i64, _i64, _p],
     "gts_spmm_sum_f32": [_p, _p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _p],
     "gts_gat_fwd_f32": [_p, _p, _p, _p, _p, _f32, _p, _p, _i32, _p, _p, _i64, _i64, _i64, _p],
     "gts_gat_scores_f32": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
@@ -59,7 +64,7 @@ SIGNATURES = {
 _RESTYPE = {"gts_error_string": ctypes.c_char_p, "gts_linear_bwd_weight_workspace": _i64,
             "gts_weighted_ce_workspace": _i64, "gts_gat_reduce_workspace": _i64,
             "gts_label_confusion_workspace": _i64, "gts_gat_fc_scores_workspace": _i64,
-            "gts_relu_bits_bytes": _i64}
+            "gts_relu_bits_bytes": _i64, "gts_cluster_record_words": _i64, "gts_cluster_lds_bytes": _i64}
 
 _lib = None
 

@@ -29,7 +29,7 @@ class _DeviceCSR:
     (a single host->device copy instead of eight) and handed out as views of it."""
 
     __slots__ = ("indptr", "indices", "t_indptr", "t_indices", "t_slot", "t_pos",
-                 "deg_clamped", "deg_plus1", "device", "packed", "__weakref__")
+                 "deg_clamped", "deg_plus1", "device", "packed", "schedules", "__weakref__")
     _INT_FIELDS = ("indptr", "indices", "t_indptr", "t_indices", "t_slot", "t_pos")
 
     def __init__(self, g, device):
@@ -44,6 +44,7 @@ class _DeviceCSR:
         for a, off in zip(parts, offsets):
             host[off:off + a.size] = a
         self.device = device
+        self.schedules = {}               # 'in' / 'out' -> _DeviceSchedule (cluster row schedules, uploaded on first use)
         self.packed = torch.from_numpy(host).to(device)
         views = [self.packed[off:off + a.size] for a, off in zip(parts, offsets)]
         for name, v in zip(self._INT_FIELDS, views):
@@ -54,12 +55,26 @@ class _DeviceCSR:
     def record_stream(self, stream):
         """The buffer was uploaded on another stream than the one that will read it."""
         self.packed.record_stream(stream)
+        for s in self.schedules.values():
+            s.packed.record_stream(stream)
+
+
+class _DeviceSchedule:
+    """Device copy of one ClusterSchedule (gts/schedule.py): its records, one upload."""
+
+    __slots__ = ("host", "packed")
+
+    def __init__(self, sched, device):
+        self.host = sched
+        self.packed = torch.from_numpy(sched.rec).to(device)
 
 
 class Graph:
     def __init__(self, src, dst, num_nodes, batch_num_nodes=None, _prebuilt=None, _members=None):
         self.n = int(num_nodes)
         self._members = _members          # batch(): COO is assembled from the members on first use
+        self._sched_members = _members    # batch(): cluster schedules are concatenated from the members' on first use
+        self._sched = {}                  # 'in' / 'out' -> ClusterSchedule or None (shared by every view)
         if _members is None:
             self._src = np.ascontiguousarray(src, dtype=np.int32)
             self._dst = np.ascontiguousarray(dst, dtype=np.int32)
@@ -183,6 +198,44 @@ class Graph:
     @property
     def arg_bytes(self):
         return 1 if self.max_in_degree <= 254 else 4
+
+    def cluster_schedule(self, which):
+        """Cluster row schedule of the in-CSR ('in': K1, rows = destinations) or of the out-CSR ('out': K2, rows =
+        sources, tagged with t_slot); None when clustering does not save enough row fetches on this graph (or a
+        row's degree is beyond a cluster).  Built once per host graph; a batch concatenates its members'."""
+        from . import schedule as _schedule
+
+        if which not in self._sched:
+            sched = None
+            if self._sched_members is not None:
+                graphs, node_off = self._sched_members
+                parts = [g.cluster_schedule(which) for g in graphs]
+                if all(p is not None for p in parts):
+                    sched = _schedule.ClusterSchedule.concat(parts, node_off)
+            else:
+                lim = _schedule.limits(which)
+                if which == "in":
+                    sched = _schedule.ClusterSchedule.build(self.indptr, self.indices, self.t_indptr, self.t_indices,
+                                                            None, lim)
+                else:
+                    sched = _schedule.ClusterSchedule.build(self.t_indptr, self.t_indices, self.indptr, self.indices,
+                                                            self.t_slot, lim)
+                if sched is not None and not sched.worthwhile():
+                    sched = None
+            self._sched[which] = sched
+        return self._sched[which]
+
+    def dev_schedule(self, which):
+        """Device copy of cluster_schedule(which) on self.device (None when there is no schedule)."""
+        sched = self.cluster_schedule(which)
+        if sched is None:
+            return None
+        d = self.dev()
+        held = d.schedules.get(which)
+        if held is None or held.host is not sched:
+            held = _DeviceSchedule(sched, self.device)
+            d.schedules[which] = held
+        return held
 
     def __repr__(self):
         return (f"Graph(num_nodes={self.n}, num_edges={self.number_of_edges()}, "

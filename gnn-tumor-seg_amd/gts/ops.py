@@ -49,14 +49,34 @@ def spmm_max_fwd(g, x, want_arg=True, relu_input=False):
     ab = g.arg_bytes if want_arg else 0
     arg = torch.empty((n, f), dtype=_ARG_DTYPE[ab], device=x.device) if want_arg else None
     lib = _lib.load()
+    ds = _cluster_schedule(g, "in", n, f, ab)
+    if ds is not None:      # LDS-staged neighbour tiles over the graph's cluster row schedule: same result, bit for bit
+        h = ds.host
 
-    def launch():
-        return lib.gts_spmm_max_fwd_f32(ptr(d.indptr), ptr(d.indices), ptr(x), ptr(out), ptr(arg),
-                                        ab, 1 if relu_input else 0, n, f, current_stream())
+        def launch():
+            return lib.gts_spmm_max_fwd_cluster_f32(ptr(ds.packed), h.n_clusters, h.limits[0], h.limits[1], h.loc_words,
+                                                    ptr(x), ptr(out), ptr(arg), ab, 1 if relu_input else 0, n, f,
+                                                    current_stream())
+    else:
+        def launch():
+            return lib.gts_spmm_max_fwd_f32(ptr(d.indptr), ptr(d.indices), ptr(x), ptr(out), ptr(arg),
+                                            ab, 1 if relu_input else 0, n, f, current_stream())
 
     code = _timed("spmm_max_fwd_f256", launch) if (f == 256 and want_arg) else launch()
     check(code, "gts_spmm_max_fwd_f32")
     return out, arg
+
+
+def _cluster_schedule(g, which, n, f, arg_bytes):
+    """Device schedule for the clustered K1 / K2 kernels, or None when they do not apply (F != 256, 4-byte
+    winners, tables of 4 GiB and more, no worthwhile schedule, GTS_CLUSTER_SPMM=0)."""
+    from . import schedule
+
+    if not schedule.ENABLED or f != 256 or arg_bytes not in (0, 1) or n * 1024 >= 2 ** 32 or n == 0:
+        return None
+    if which == "in" and n < schedule.MIN_ROWS_FORWARD:
+        return None
+    return g.dev_schedule(which)
 
 
 def spmm_max_bwd(g, gout, arg, relu_src=None):
@@ -74,11 +94,18 @@ def spmm_max_bwd(g, gout, arg, relu_src=None):
         raise _lib.GtsError(f"arg dtype {arg.dtype} does not belong to this graph ({_ARG_DTYPE[g.arg_bytes]})")
     gx = torch.empty((n, f), dtype=torch.float32, device=gout.device)
     lib = _lib.load()
+    ds = _cluster_schedule(g, "out", n, f, arg.element_size()) if relu_src is None else None
+    if ds is not None:
+        h = ds.host
 
-    def launch():
-        return lib.gts_spmm_max_bwd_f32(ptr(d.t_indptr), ptr(d.t_indices), ptr(d.t_slot), ptr(gout),
-                                        ptr(arg), arg.element_size(), ptr(relu_src), ptr(gx), n, f,
-                                        current_stream())
+        def launch():
+            return lib.gts_spmm_max_bwd_cluster_f32(ptr(ds.packed), h.n_clusters, h.limits[0], h.limits[1], h.loc_words,
+                                                    ptr(gout), ptr(arg), 1, ptr(gx), n, f, current_stream())
+    else:
+        def launch():
+            return lib.gts_spmm_max_bwd_f32(ptr(d.t_indptr), ptr(d.t_indices), ptr(d.t_slot), ptr(gout),
+                                            ptr(arg), arg.element_size(), ptr(relu_src), ptr(gx), n, f,
+                                            current_stream())
 
     check(_timed("spmm_max_bwd_f256", launch) if f == 256 else launch(), "gts_spmm_max_bwd_f32")
     return gx

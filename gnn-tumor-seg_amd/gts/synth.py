@@ -61,6 +61,31 @@ def random_graph(n=15000, n_pairs=30000, seed=1000):
     return Graph(src[order], dst[order], n)
 
 
+def geometric_graph(n=6000, k=8, seed=1000, self_loops=False):
+    """Generator C ("SLIC-like"): n uniform random points in the unit cube, each joined to its k nearest
+    neighbours, symmetrised; node ids in raster order of a 16^3 grid of cells (roughly the order SLIC labels
+    come in).  Irregular degrees (k .. ~2k), spatial locality without a lattice.  Optional self-loops, as the
+    reference's touching-adjacency graphs have (mri2graph/graphgen.py:189)."""
+    from scipy.spatial import cKDTree
+
+    rng = np.random.default_rng(seed)
+    pts = rng.random((n, 3))
+    cell = np.floor(pts * 16).astype(np.int64)
+    order = np.lexsort((pts[:, 2], cell[:, 2], cell[:, 1], cell[:, 0]))
+    pts = pts[order]
+    _, nbr = cKDTree(pts).query(pts, k=k + 1)
+    a = np.repeat(np.arange(n), k)
+    b = nbr[:, 1:].reshape(-1)
+    und = np.unique(np.sort(np.stack([a, b], 1), 1), axis=0)
+    src = np.concatenate([und[:, 0], und[:, 1]])
+    dst = np.concatenate([und[:, 1], und[:, 0]])
+    if self_loops:
+        src = np.concatenate([src, np.arange(n)])
+        dst = np.concatenate([dst, np.arange(n)])
+    order = np.lexsort((dst, src))
+    return Graph(src[order], dst[order], n)
+
+
 def node_features(n, in_feats=4, seed=1000):
     rng = np.random.default_rng(seed)
     return rng.standard_normal((n, in_feats)).astype(np.float32)
@@ -80,6 +105,9 @@ def make_sample(g_index, kind="lattice", n=15000, in_feats=4):
         g = lattice_graph()
     elif kind == "random":
         g = random_graph(n=n, n_pairs=2 * n, seed=seed)
+    elif kind == "selfloop":      # every node its own only neighbour: the reducers become row copies (what-if runs)
+        ids = np.arange(n)
+        g = Graph(ids, ids, n)
     else:
         raise ValueError(kind)
     return f"synth_{kind}_{g_index:04d}", g, node_features(g.n, in_feats, seed), node_labels(g.n, seed)

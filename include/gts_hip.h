@@ -62,6 +62,48 @@ int32_t gts_spmm_max_bwd_f32(const int32_t* t_indptr, const int32_t* t_indices,
                              int32_t arg_bytes, const float* relu_src, float* gx,
                              int64_t n_src, int64_t n_feat, void* stream);
 
+/* ---- K1 / K2 over a cluster row schedule (F = 256): LDS-staged neighbour tiles ---------------
+ * Same operators as gts_spmm_max_fwd_f32 / gts_spmm_max_bwd_f32 (DGL copy_u + max inside SAGEConv('pool'),
+ * model/networks.py:25,28,30, and its autograd), bit-identical results, different work distribution: the rows
+ * of the CSR are dealt to workgroups as clusters that share their neighbour rows; persistent workgroups stage
+ * each distinct neighbour row of a cluster in LDS once (LDS-DMA, several clusters ahead) instead of fetching
+ * one row per edge behind a chain of dependent index loads.
+ *
+ * gts_cluster_schedule (HOST function: host pointers, no GPU call) builds the schedule of one CSR once per
+ * graph: (indptr, indices) is the CSR to schedule, (t_indptr, t_indices) its transpose, edge_tag an optional
+ * per-edge payload in 0..255 (K2: t_slot).  A cluster holds <= max_rows rows, <= max_srcs (<= 256) distinct
+ * neighbours and <= max_edges (<= 65535) PADDED edges (every row's edge list is padded to whole chunks of 8);
+ * rows keep their edges in CSR slot order.  One fixed-size RECORD per cluster is written to rec[c * W ...],
+ * W = gts_cluster_record_words(max_rows, max_srcs, LW, with_tag) int32 words with LW = ((max_edges + 3) / 4
+ * rounded up to a multiple of 4):
+ *   words 0..3: n_rows, n_srcs, padded edges, 0 | row ids [max_rows] | neighbour ids [max_srcs] (entries
+ *   past n_srcs repeat the last one) | per row [max_rows]: index of its first 8-edge chunk (low 16 bits),
+ *   degree (high 16 bits) | uint8 per padded edge: position of its neighbour in the cluster's list [4 LW]
+ *   (pads repeat the row's last edge) | uint8 per padded edge: its tag [4 LW] (only with edge_tag); every
+ *   section starts on a multiple of 4 words.
+ * rec may be NULL (count only); at most rec_capacity records are written.  Outputs: the number of clusters,
+ * the neighbour rows staged over all clusters, the largest padded edge count of a cluster (a caller may re-pack the
+ * records with a smaller LW).  Returns GTS_ERR_SHAPE when a row's degree exceeds max_srcs / max_edges or a tag
+ * does not fit a byte, GTS_ERR_ARGKIND for limits outside the ranges above or records above 512 words.
+ * gts_cluster_lds_bytes: LDS bytes of one ring slot for (max_rows, max_srcs, LW), kind 0 = forward, 1 =
+ * backward; the kernels need at least two slots in the CU's 160 KiB.
+ * The device entry points take a DEVICE copy of the records (stride W for the LW passed); n_feat must be 256,
+ * arg_bytes 0 / 1 (forward) or 1 (backward), n_rows * 1024 < 2^32. */
+int64_t gts_cluster_record_words(int32_t max_rows, int32_t max_srcs, int32_t loc_words, int32_t with_tag);
+int32_t gts_cluster_schedule(const int32_t* indptr, const int32_t* indices, const int32_t* t_indptr,
+                             const int32_t* t_indices, const int32_t* edge_tag, int64_t n_rows,
+                             int32_t max_rows, int32_t max_srcs, int32_t max_edges, int32_t* rec,
+                             int64_t rec_capacity, int64_t* n_clusters, int64_t* n_staged,
+                             int32_t* max_cluster_edges);
+int64_t gts_cluster_lds_bytes(int32_t max_rows, int32_t max_srcs, int32_t loc_words, int32_t kind);
+int32_t gts_spmm_max_fwd_cluster_f32(const int32_t* rec, int64_t n_clusters, int32_t max_rows, int32_t max_srcs,
+                                     int32_t loc_words, const float* x, float* out, void* arg,
+                                     int32_t arg_bytes, int32_t relu_input, int64_t n_rows, int64_t n_feat,
+                                     void* stream);
+int32_t gts_spmm_max_bwd_cluster_f32(const int32_t* rec, int64_t n_clusters, int32_t max_rows, int32_t max_srcs,
+                                     int32_t loc_words, const float* gout, const void* arg, int32_t arg_bytes,
+                                     float* gx, int64_t n_rows, int64_t n_feat, void* stream);
+
 /* ---- K3/K4: copy_u + sum / mean / gcn reducers (forward and backward) ---------------
  * Replaces DGL update_all(copy_u, sum|mean) of SAGEConv('mean'|'gcn')
  * (model/networks.py:73,75 via :25-30) and, on the out-CSR, their autograd.
@@ -300,6 +342,12 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
                                 2 = non-temporal stores of the output panel (direct-to-fragment kernels; no gain measured),
                                 4 = the direct-to-fragment kernels keep every epilogue switch a run-time argument (the generic
                                     instantiation) instead of the compile-time epilogues of the layer-stack launches (A/B runs) */
+#define GTS_OPT_CLUSTER_STREAMING 8 /* clustered K1 / K2: bit 0 = non-temporal stores of out / gx; -1 = per-kernel default */
+#define GTS_OPT_CLUSTER_KERNEL 9     /* clustered K1 / K2: 0 = persistent streaming workgroups (default), 1 = one workgroup per unit,
+                                        2 = persistent workgroups with loader waves feeding a ring of slots to consumer waves */
+#define GTS_OPT_CLUSTER_RING 10      /* form 2: ring slots per workgroup (0 = as many as fit, at most 4) */
+#define GTS_OPT_CLUSTER_PER_CU 11    /* forms 0 / 2: persistent workgroups per CU (0 = automatic) */
+#define GTS_OPT_CLUSTER_CONSUMERS 12 /* form 0: waves per workgroup (default 8); form 2: consumer waves (0 = automatic) */
 int32_t gts_set_option(int32_t option, int32_t value);
 
 #ifdef __cplusplus
