@@ -32,7 +32,13 @@ Rank 0 prints ONE JSON line with the throughput, plus
 
 Other BASELINE.json configurations (parity-test cases, not the headline) can be timed with
   --config c3   GAT 4 layers x 4 heads x 256 training on the same graphs   (graphs/s)
+  --config c4   the C2 model at 8 graphs per rank: with --gpus 8 this is BASELINE.json's data-parallel
+                configuration (global batch 64, RCCL gradient all-reduce); with --gpus 1 its per-GPU workload
   --config c5   batched no-grad forward + node->voxel logits projection to 240^3 (volumes/s)
+  --config real the reference's own training workload (utils/hyperparam_helpers.py:36-39, model/gnn_model.py:12):
+                in_feats 20, layer_sizes [256]*4, batches of 6 graphs of ~6k nodes (18^3 lattices), every step a
+                FRESH batch collated on the host and uploaded through GNN's prefetch path (graphs/s, with the
+                resident-batch rate and the host enqueue time beside it)
 """
 import argparse
 import contextlib
@@ -62,6 +68,13 @@ CONFIGS = {
     "c2": dict(model="GSpool", layer_sizes=[256] * 7, heads=None, residuals=None,
                metric="supervoxel-graphs/sec training, 7xSAGE-pool-256, 15k-node graphs",
                hbm_kernels=("spmm_max_fwd_f256", "spmm_max_bwd_f256")),
+    "c4": dict(model="GSpool", layer_sizes=[256] * 7, heads=None, residuals=None, graphs_per_gpu=8,
+               metric="supervoxel-graphs/sec training, 7xSAGE-pool-256, 15k-node graphs",
+               hbm_kernels=("spmm_max_fwd_f256", "spmm_max_bwd_f256")),
+    "real": dict(model="GSpool", layer_sizes=[256] * 4, heads=None, residuals=None, graphs_per_gpu=6, in_feats=20,
+                 metric="supervoxel-graphs/sec training, the reference's own workload: 4xSAGE-pool-256, in_feats 20, "
+                        "6 graphs of ~6k nodes per step, fresh batches",
+                 hbm_kernels=("spmm_max_fwd_f256", "spmm_max_bwd_f256")),
     "c3": dict(model="GAT", layer_sizes=[256] * 4, heads=[4] * 4, residuals=[False] * 4,
                metric="supervoxel-graphs/sec training, GAT 4 layers x 4 heads x 256, 15k-node graphs",
                hbm_kernels=("gat_fwd",)),
@@ -78,12 +91,16 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--blocks", type=int, default=10,
                     help="the --steps block is timed this many times; value = the median block")
-    ap.add_argument("--graphs-per-gpu", type=int, default=4)
+    ap.add_argument("--graphs-per-gpu", type=int, default=None,
+                    help="graphs in one rank's batch (default 4; 8 for --config c4, 6 for --config real)")
     ap.add_argument("--graph-kind", default="lattice", choices=["lattice", "random", "selfloop"])
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.graphs_per_gpu is None:
+        args.graphs_per_gpu = CONFIGS[args.config].get("graphs_per_gpu", 4)
+    return args
 
 
 def log(msg):
@@ -119,15 +136,48 @@ class KernelTimers:
                 "work": float(sum(w for _, _, w in pairs))}
 
 
-def build_batches(rank, graphs_per_gpu, kind, n_batches, device):
+REAL_DIMS = (18, 18, 18)     # 5 832 nodes: "less than half" of the 15k requested supervoxels survive (mri2graph/graphgen.py:210-211)
+
+
+def real_sample(g_index, in_feats):
+    """One sample of the reference's real shape: ~6k-node supervoxel graph (lattice), float64 features as its
+    loader yields them (data_processing/data_loader.py:67-83)."""
+    from gts import synth
+
+    g = synth.lattice_graph(REAL_DIMS)
+    seed = 1000 + g_index
+    return (f"synth_real_{g_index:04d}", g, synth.node_features(g.n, in_feats, seed).astype(np.float64),
+            synth.node_labels(g.n, seed))
+
+
+class RealDataset(torch.utils.data.Dataset):
+    """In-memory stand-in for ImageGraphDataset at the reference's real shape (same item layout)."""
+
+    def __init__(self, n_samples, in_feats):
+        self.items = [real_sample(i, in_feats) for i in range(n_samples)]
+        self.read_label = True
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def build_batches(rank, graphs_per_gpu, kind, n_batches, device, cfg=None):
     """Distinct synthetic batches for this rank, uploaded once (graph g uses seed 1000+g)."""
     import gts
     from gts import synth
 
+    in_feats = (cfg or {}).get("in_feats", IN_FEATS)
     batches = []
     for b in range(n_batches):
         first = (rank * n_batches + b) * graphs_per_gpu
-        samples = [synth.make_sample(first + i, kind=kind, in_feats=IN_FEATS) for i in range(graphs_per_gpu)]
+        if in_feats != IN_FEATS:      # --config real
+            samples = [real_sample(first + i, in_feats) for i in range(graphs_per_gpu)]
+            samples = [(s[0], s[1], s[2].astype(np.float32), s[3]) for s in samples]
+        else:
+            samples = [synth.make_sample(first + i, kind=kind, in_feats=IN_FEATS) for i in range(graphs_per_gpu)]
         g = gts.batch([s[1] for s in samples]).to(device)
         g.dev()  # upload CSR now, not inside the timed region
         feats = torch.from_numpy(np.concatenate([s[2] for s in samples])).to(device)
@@ -151,8 +201,8 @@ def host_cores():
 def hyperparams(cfg):
     from utils.hyperparam_helpers import FullParamSet
 
-    return FullParamSet(1, IN_FEATS, N_CLASSES, 1e-4, 0.98, 1e-4, CLASS_WEIGHTS, cfg["layer_sizes"], 0,
-                        cfg["heads"], cfg["residuals"])
+    return FullParamSet(1, cfg.get("in_feats", IN_FEATS), N_CLASSES, 1e-4, 0.98, 1e-4, CLASS_WEIGHTS,
+                        cfg["layer_sizes"], 0, cfg["heads"], cfg["residuals"])
 
 
 def cpu_baseline(cfg, graphs_per_gpu, kind, steps):
@@ -166,7 +216,11 @@ def cpu_baseline(cfg, graphs_per_gpu, kind, steps):
     torch.manual_seed(0)
     net = torch_ref.ref_init_graph_net(cfg["model"], hyperparams(cfg))
     opt = torch_ref.make_optimizer(net)
-    samples = [synth.make_sample(i, kind=kind, in_feats=IN_FEATS) for i in range(graphs_per_gpu)]
+    if "in_feats" in cfg:
+        samples = [real_sample(i, cfg["in_feats"]) for i in range(graphs_per_gpu)]
+        samples = [(s[0], s[1], s[2].astype(np.float32), s[3]) for s in samples]
+    else:
+        samples = [synth.make_sample(i, kind=kind, in_feats=IN_FEATS) for i in range(graphs_per_gpu)]
     ref = graph_ref.batch_ref([graph_ref.RefGraph(s[1].src, s[1].dst, s[1].n) for s in samples])
     tg = torch_ref.TGraph(ref)
     feats = torch.from_numpy(np.concatenate([s[2] for s in samples]))
@@ -182,7 +236,7 @@ def cpu_baseline(cfg, graphs_per_gpu, kind, steps):
     dt = time.perf_counter() - t0
     return {"value": graphs_per_gpu * steps / dt, "unit": "graphs/s", "cores": cores, "kind": "port",
             "sample": f"{steps} training steps (+1 warm-up) of the same batch of {graphs_per_gpu} "
-                      f"15k-node {kind} graphs, {cfg['model']} {cfg['layer_sizes']}, fp32, torch CPU oracle"}
+                      f"{samples[0][1].n}-node {kind} graphs, {cfg['model']} {cfg['layer_sizes']}, fp32, torch CPU oracle"}
 
 
 def algorithmic_bytes(kernel, n_b, e_b, arg_bytes, heads=4, dim=256, n_vox=240 ** 3):
@@ -250,12 +304,13 @@ def main():
 
     _lib.load()
     torch.manual_seed(0)
+    dataset = RealDataset(8 * args.graphs_per_gpu, cfg["in_feats"]) if args.config == "real" else None
     with contextlib.redirect_stdout(sys.stderr):   # stdout carries the JSON line only
-        model = GNN(cfg["model"], hyperparams(cfg), None)
+        model = GNN(cfg["model"], hyperparams(cfg), dataset, batch_size=args.graphs_per_gpu)
     if world > 1:
         gdist.broadcast_parameters(model.net.parameters(), src=0)
         model.grad_sync = gdist.FlatGradSync(model.net.parameters())
-    batches = build_batches(rank, args.graphs_per_gpu, args.graph_kind, n_batches=2, device=device)
+    batches = build_batches(rank, args.graphs_per_gpu, args.graph_kind, n_batches=2, device=device, cfg=cfg)
     n_b, e_b = batches[0][0].n, batches[0][0].number_of_edges()
 
     timers = KernelTimers()
@@ -277,6 +332,22 @@ def main():
                 vols = [ops.project_rows(svs, logits[k * per_graph:(k + 1) * per_graph], bg)
                         for k in range(args.graphs_per_gpu)]
             return vols[-1][0, 0, 0, 0]
+    elif args.config == "real":
+        model.net.train()
+
+        def fresh_batches():      # what GNN.run_epoch iterates: collate on the host, upload on the copy stream, one step ahead
+            while True:
+                for batch in model._device_batches():
+                    yield batch
+        stream_of_batches = fresh_batches()
+
+        def step(i):
+            batch = next(stream_of_batches)
+            return model.empty_step() if batch is None else model.train_step(*batch)
+
+        def resident_step(i):
+            g, feats, labels = batches[i % len(batches)]
+            return model.train_step(g, feats, labels)
     else:
         model.net.train()
 
@@ -289,7 +360,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def timed_block():
+    def timed_block(step=step):
         """EXACTLY --steps steps between two fences; (seconds [max over ranks], host enqueue s, last)."""
         fence()
         t0 = time.perf_counter()
@@ -318,6 +389,8 @@ def main():
     timers.enabled = True
     instrumented = timed_block()[0]
     timers.enabled = False
+    # --config real: the same steps on two RESIDENT batches (every rank; the blocks fence collectively): what the host path costs
+    resident = sorted(timed_block(resident_step)[0] for _ in range(3))[1] if args.config == "real" else None
     log(f"blocks: median {elapsed:.4f} s, min {times[0]:.4f}, max {times[-1]:.4f} for {args.steps} steps; "
         f"instrumented block {instrumented:.4f} s (host enqueue {1e3 * host_enqueue / args.steps:.2f} ms/step)")
     global_batch = args.graphs_per_gpu * world
@@ -336,6 +409,11 @@ def main():
 
         workloads = {
             "c2": "C2: 7xGraphSAGE-pool-256 (8 SAGEConv), fwd+weighted-CE+bwd+AdamW",
+            "c4": "C4: 7xGraphSAGE-pool-256 (8 SAGEConv) data-parallel, fwd+weighted-CE+bwd+gradient all-reduce+AdamW, "
+                  f"global batch {args.graphs_per_gpu * world} graphs over {world} GPU(s) (BASELINE.json: 64 over 8)",
+            "real": "the reference's training workload: 4xGraphSAGE-pool-256 (5 SAGEConv), in_feats 20, "
+                    "fwd+weighted-CE+bwd+AdamW through GNN's loader path (fresh batch every step: host collate + upload "
+                    "one step ahead)",
             "c3": "C3: GAT 4 layers x 4 heads x 256 (5 GATConv), fwd+weighted-CE+bwd+AdamW",
             "c5": "C5: no-grad forward of 7xGraphSAGE-pool-256 + logits projection of every graph to an "
                   "int16 240^3 partition (fp32 x4 rows)",
@@ -347,9 +425,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{workloads[args.config]}, {args.graphs_per_gpu} x 15k-node/"
+            "config": {"workload": f"{workloads[args.config]}, {args.graphs_per_gpu} x {n_b // args.graphs_per_gpu}-node/"
                                    f"{e_b // args.graphs_per_gpu}-edge {args.graph_kind} graphs per GPU, "
-                                   "4-chan feat, fp32",
+                                   f"{cfg.get('in_feats', IN_FEATS)}-chan feat, fp32",
                        "global_batch": global_batch, "nodes_per_batch": n_b, "edges_per_batch": e_b,
                        "parallelism": f"dp{world}", "last_value": round(float(last), 6),
                        "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 3)},
@@ -359,6 +437,9 @@ def main():
             "ranks": world,
             "backend": torch.distributed.get_backend() if world > 1 else None,
         }
+        if resident is not None:
+            result["config"]["resident_batches"] = {"value": round(rate(resident), 3),
+                                                    "ms_per_step": round(1e3 * resident / args.steps, 4)}
         # --- K11, where most of the step goes (all three GEMM forms are one kernel template)
         kinds = {k: timers.summary("gemm_" + k) for k in ("fwd", "igrad", "wgrad")}
         kinds = {k: v for k, v in kinds.items() if v}

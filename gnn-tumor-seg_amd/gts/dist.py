@@ -66,6 +66,32 @@ def shard_indices(perm, step, per_rank, rank, world_size):
     return list(perm[step * g:(step + 1) * g][rank::world_size])
 
 
+def rank_share(n_items):
+    """Indices of this rank when `n_items` independent items (evaluation samples, volumes to predict) are dealt
+    round-robin over the ranks: rank r takes r, r + W, ...  Everything when torch.distributed is not initialised."""
+    rank, w = world()
+    return list(range(rank, n_items, w))
+
+
+def gather_rows_in_order(n_items, mine):
+    """`mine` maps the indices of rank_share(n_items) to picklable rows (metric vectors of this rank's samples).
+    Returns the list of all n_items rows in index order, identical on every rank (one all_gather_object on
+    the host side: evaluation has no device collective)."""
+    _, w = world()
+    if w == 1:
+        everyone = [mine]
+    else:
+        everyone = [None] * w
+        dist.all_gather_object(everyone, mine)
+    rows = {}
+    for part in everyone:
+        rows.update(part)
+    missing = [i for i in range(n_items) if i not in rows]
+    if missing:
+        raise RuntimeError(f"items {missing[:8]} were evaluated by no rank")
+    return [rows[i] for i in range(n_items)]
+
+
 def broadcast_object(obj, src=0):
     """`obj` of rank `src` on every rank (anything picklable: hyper-parameter tuples, seeds).
     Identity when torch.distributed is not initialised."""

@@ -239,14 +239,22 @@ class GNN:
         produces (tests/test_gpu_cli.py).  Everything up to the Dice quotients stays on the GPU:
         arg-max + projection is one K12 pass per sample, the node- and voxel-level label
         coincidences are counted by K15, and only the two 5x5 integer tables, the loss and the
-        predicted volume (for the scipy distance transforms of HD95) travel to the host."""
+        predicted volume (for the scipy distance transforms of HD95) travel to the host.
+
+        Under torch.distributed the samples are dealt round-robin over the ranks (rank r evaluates r, r + W, ...:
+        forwards AND the host-side HD95 transforms), the per-sample rows are gathered on the host and every rank
+        returns the same two arrays — the doubles a single process computes, because a sample's row does not
+        depend on what it is batched with (tests/test_gpu_dp.py)."""
         assert dataset.dataset.read_label == True  # noqa: E712
         self.net.eval()
         source = dataset.dataset        # Subset -> underlying ImageGraphDataset
-        metric_rows, count_rows = [], []
         n_samples = len(dataset)
-        for first in range(0, n_samples, max(1, int(batch_size))):
-            samples = [dataset[i] for i in range(first, min(n_samples, first + max(1, int(batch_size))))]
+        share = gdist.rank_share(n_samples)
+        rows = {}
+        step = max(1, int(batch_size))
+        for first in range(0, len(share), step):
+            indices = share[first:first + step]
+            samples = [dataset[i] for i in indices]
             ids, graph, feats, labels = minibatch_graphs(samples)
             graph, feats, labels = self._to_device(graph, feats, labels)
             with torch.no_grad(), gdense.row_count_invariant():
@@ -266,11 +274,12 @@ class GNN:
                         predicted_voxels, torch.from_numpy(true_voxels).to(self.device).contiguous())
                 tables = torch.stack([node_table, voxel_table]).cpu().numpy()
                 hd95s = evaluation.calculate_hd95s(predicted_voxels.cpu().numpy(), true_voxels)
-                metric_rows.append(np.concatenate([[loss.item()], evaluation.dices_from_confusion(tables[0]),
-                                                   evaluation.dices_from_confusion(tables[1]), hd95s]))
-                count_rows.append(evaluation.label_counts_from_confusion(tables[0]))
-        metrics = np.array(metric_rows).reshape(len(metric_rows), 10)
-        counts = np.array(count_rows).reshape(len(count_rows), 8)
+                rows[indices[j]] = (np.concatenate([[loss.item()], evaluation.dices_from_confusion(tables[0]),
+                                                    evaluation.dices_from_confusion(tables[1]), hd95s]),
+                                    evaluation.label_counts_from_confusion(tables[0]))
+        rows = gdist.gather_rows_in_order(n_samples, rows)
+        metrics = np.array([r[0] for r in rows]).reshape(n_samples, 10)
+        counts = np.array([r[1] for r in rows]).reshape(n_samples, 8)
         return np.mean(metrics, axis=0), np.sum(counts, axis=0)
 
     def calculate_all_metrics_for_brain(self, mri_id, dataset, node_preds, node_labels):

@@ -3,7 +3,10 @@
 Command line, outputs and file names match /root/reference/scripts/train_gnn.py:64-89:
   python -m scripts.train_gnn -d DATA -o LOGDIR -r RUN [-m GSpool|GSmean|GSgcn|GAT] [-k FOLDS]
                               [-p PREFIX] [-x]
-Launch under `torchrun --nproc-per-node N` for data-parallel training (one rank per GPU).
+Launch under `torchrun --nproc-per-node N` for data-parallel training (one rank per GPU).  By default every
+rank then takes the reference's batch of 6 graphs per step (global batch 6 N at the reference's learning rate:
+weak scaling); `--keep_global_batch` splits the reference's 6 over the ranks instead (ceil(6 / N) each), which is
+the optimisation problem of the single-GPU run.  Evaluation is sharded over the ranks either way.
 """
 import argparse
 import os
@@ -39,7 +42,7 @@ def document_metrics(fp, description, results):
 
 def train_on_full_dataset(args, hyperparams, progress_file_fd, dataset):
     print("Training on full dataset")
-    model = GNN(args.model_type, hyperparams, dataset)
+    model = GNN(args.model_type, hyperparams, dataset, keep_global_batch=args.keep_global_batch)
     train_on_fold(model, args.output_dir + os.sep, hyperparams.n_epochs, args.run_name, 1)
     whole = Subset(dataset, range(len(dataset)))
     document_metrics(progress_file_fd, f"{args.run_name}_full", model.evaluate(whole))
@@ -53,7 +56,7 @@ def run_k_fold_val(args, hyperparams, progress_file_fd, dataset, k):
         held_out = Subset(dataset, range(start, end))
         training = Subset(dataset, list(r_[0:start, end:everything]))
         print(f"Fold contains {len(training)} examples")
-        model = GNN(args.model_type, hyperparams, training)
+        model = GNN(args.model_type, hyperparams, training, keep_global_batch=args.keep_global_batch)
         train_on_fold(model, args.output_dir + os.sep, hyperparams.n_epochs, args.run_name, fold)
         for split, subset in (("train", training), ("val", held_out)):
             document_metrics(progress_file_fd, f"{args.run_name}_f{fold}_{split}", model.evaluate(subset))
@@ -77,6 +80,9 @@ def build_parser():
         parser.add_argument(short, long_name, default=default, type=kind, help=text)
     parser.add_argument("-x", "--random_hyperparams", default=False, action="store_true",
                         help="draw random hyper-parameters")
+    parser.add_argument("--keep_global_batch", default=False, action="store_true",
+                        help="data-parallel runs: split the reference's batch of 6 graphs over the ranks instead of "
+                             "giving every rank 6 (not a flag of the reference, which is single-device)")
     return parser
 
 

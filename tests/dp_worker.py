@@ -55,3 +55,33 @@ def run_rank(rank, world, port, n_samples, out_dir):
                os.path.join(out_dir, f"rank{rank}.pt"))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
+
+
+def run_eval_rank(rank, world, port, data_dir, ckpt, out_dir):
+    """One rank of a sharded GNN.evaluate + prediction run over the file dataset in `data_dir` (two ranks share
+    the one GPU; gloo carries the host-side gather)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), GTS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import io
+    from contextlib import redirect_stdout
+
+    from data_processing.data_loader import ImageGraphDataset
+    from gts import dist as gdist
+    from model.gnn_model import GNN
+    from scripts import generate_gnn_predictions as gen
+    from utils.hyperparam_helpers import FullParamSet
+
+    gdist.init_from_env()
+    with redirect_stdout(io.StringIO()):
+        ds = ImageGraphDataset(data_dir, "BraTS_", read_image=False, read_graph=True, read_label=True)
+        hp = FullParamSet(3, 20, 4, 5e-3, 0.98, 1e-4, [0.1, 1, 2, 2], [64, 64], 0, None, None)
+        model = GNN("GSpool", hp, None)
+        model.net.load_state_dict(torch.load(ckpt, map_location=model.device, weights_only=True))
+        metrics, counts = model.evaluate(torch.utils.data.Subset(ds, list(range(len(ds)))), batch_size=2)
+        unl = ImageGraphDataset(data_dir, "BraTS_", read_image=False, read_graph=True, read_label=False)
+        gen.output_dir = os.path.join(out_dir, "preds")
+        os.makedirs(gen.output_dir, exist_ok=True)
+        gen.save_predictions(model.net, unl, "preds")
+    np.savez(os.path.join(out_dir, f"eval{rank}.npz"), metrics=metrics, counts=counts)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()

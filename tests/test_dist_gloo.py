@@ -224,3 +224,54 @@ def test_two_rank_epoch_keeps_the_partial_last_batch_and_one_hyperparameter_draw
         assert torch.allclose(p.detach(), q, rtol=1e-4, atol=1e-6)
     with pytest.raises(ValueError):
         _ShardedBatches(MemDataset(0), 1, 0, 2)
+
+
+# ------------------------------------------------------------------ sharded evaluation: rows gathered on the host
+def _row_of(i):
+    """A stand-in for one sample's (metrics[10], counts[8]) row of GNN.evaluate (model/gnn_model.py; the reference
+    computes them sample by sample, /root/reference/model/gnn_model.py:51-74)."""
+    rng = np.random.default_rng(1000 + i)
+    return rng.standard_normal(10), rng.integers(0, 500, size=8)
+
+
+def _gather_worker(rank, world, port, n_items, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    gdist.init_from_env(backend="gloo")
+    share = gdist.rank_share(n_items)
+    rows = gdist.gather_rows_in_order(n_items, {i: _row_of(i) for i in share})
+    metrics = np.mean(np.array([r[0] for r in rows]).reshape(n_items, 10), axis=0)
+    counts = np.sum(np.array([r[1] for r in rows]).reshape(n_items, 8), axis=0)
+    np.savez(os.path.join(out_dir, f"gather{rank}.npz"), share=np.array(share), metrics=metrics, counts=counts)
+    if rank == 1 and n_items:          # a rank that skips one of its samples is noticed by every rank
+        broken = {i: _row_of(i) for i in share[1:]}
+    else:
+        broken = {i: _row_of(i) for i in share}
+    try:
+        gdist.gather_rows_in_order(n_items, broken)
+        failed = False
+    except RuntimeError:
+        failed = True
+    assert failed == (n_items > 1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [7, 2, 1])
+def test_two_rank_sharded_rows_equal_the_single_process_doubles(tmp_path, n_items):
+    world = 2
+    mp.spawn(_gather_worker, args=(world, _free_port(), n_items, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"gather{r}.npz") for r in range(world)]
+    assert sorted(np.concatenate([p["share"] for p in parts]).tolist()) == list(range(n_items))   # dataset[rank::W]
+    rows = [_row_of(i) for i in range(n_items)]
+    want_m = np.mean(np.array([r[0] for r in rows]).reshape(n_items, 10), axis=0)
+    want_c = np.sum(np.array([r[1] for r in rows]).reshape(n_items, 8), axis=0)
+    for p in parts:                                              # identical return value on every rank, bit for bit
+        assert np.array_equal(p["metrics"], want_m) and np.array_equal(p["counts"], want_c)
+
+
+def test_rank_share_and_gather_without_a_process_group():
+    assert gdist.rank_share(5) == [0, 1, 2, 3, 4]
+    assert gdist.gather_rows_in_order(3, {0: "a", 1: "b", 2: "c"}) == ["a", "b", "c"]
+    with pytest.raises(RuntimeError):
+        gdist.gather_rows_in_order(3, {0: "a", 2: "c"})

@@ -52,3 +52,53 @@ def test_two_rank_epoch_matches_single_process_global_batches(tmp_path, hip_lib)
     for k, v in single.net.state_dict().items():
         assert torch.allclose(v.cpu(), ranks[0]["state"][k], rtol=1e-4, atol=1e-6), k
     assert isinstance(init_graph_net("GSpool", hp), torch.nn.Module)
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_evaluate_and_predict_equal_the_single_process_run(tmp_path, hip_lib):
+    """GNN.evaluate shards the samples over the ranks (dataset[rank::W]) and gathers the per-sample rows on the host:
+    every rank returns the doubles of the single-process evaluation (reference loop:
+    /root/reference/model/gnn_model.py:51-74); the prediction script deals the volumes the same way and the union of
+    what the ranks wrote equals the single-process output, byte for byte."""
+    import os
+
+    import numpy as np
+
+    from data_processing.data_loader import ImageGraphDataset
+    from model.gnn_model import GNN
+    from scripts import generate_gnn_predictions as gen
+    from tests.dataset_util import write_dataset
+    from utils.hyperparam_helpers import FullParamSet
+
+    data = str(tmp_path / "data") + "/"
+    write_dataset(data, 5)
+    with redirect_stdout(io.StringIO()):
+        ds = ImageGraphDataset(data, "BraTS_", read_image=False, read_graph=True, read_label=True)
+        hp = FullParamSet(3, 20, 4, 5e-3, 0.98, 1e-4, [0.1, 1, 2, 2], [64, 64], 0, None, None)
+        torch.manual_seed(0)
+        model = GNN("GSpool", hp, ds, batch_size=2)
+        for _ in range(2):
+            model.run_epoch()
+        ckpt = str(tmp_path / "w.pt")
+        torch.save(model.net.state_dict(), ckpt)
+        want = model.evaluate(torch.utils.data.Subset(ds, list(range(len(ds)))))
+        single_dir = str(tmp_path / "single")
+        os.makedirs(single_dir)
+        gen.output_dir = single_dir
+        gen.save_predictions(model.net, ImageGraphDataset(data, "BraTS_", read_image=False, read_graph=True,
+                                                          read_label=False), "preds")
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out_dir = str(tmp_path / "ranks")
+    os.makedirs(out_dir)
+    mp.spawn(dp_worker.run_eval_rank, args=(world, port, data, ckpt, out_dir), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(os.path.join(out_dir, f"eval{r}.npz"))
+        assert np.array_equal(got["metrics"], want[0]) and np.array_equal(got["counts"], want[1])
+    files = sorted(os.listdir(single_dir))
+    assert len(files) == 5 and sorted(os.listdir(os.path.join(out_dir, "preds"))) == files
+    import gzip
+    for f in files:      # the gzip header carries a time stamp: compare the volumes inside
+        assert gzip.open(os.path.join(single_dir, f)).read() == gzip.open(os.path.join(out_dir, "preds", f)).read()

@@ -23,7 +23,7 @@ from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "spmm_max" in r["Kernel_Name"]:
+        if "spmm_max" in r["Kernel_Name"] or "spmm_cluster" in r["Kernel_Name"]:
             acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in acc.items():
     print(k, {c: sum(x) / len(x) for c, x in v.items()})

@@ -24,7 +24,11 @@ def per_kernel(directory, counter):
 
 def short(name):
     for key, label in (("spmm_max_fwd_kernel<4, 64, 1>", "spmm_max_fwd_f256"),
-                       ("spmm_max_bwd_kernel<4, 64, 1>", "spmm_max_bwd_f256")):
+                       ("spmm_max_bwd_kernel<4, 64, 1>", "spmm_max_bwd_f256"),
+                       ("spmm_cluster_stream_kernel<false, 1", "spmm_max_fwd_f256"),      # the clustered forms of K1 / K2
+                       ("spmm_cluster_stream_kernel<true, 1", "spmm_max_bwd_f256"),
+                       ("spmm_cluster_unit_kernel<false, 1", "spmm_max_fwd_f256"),
+                       ("spmm_cluster_unit_kernel<true, 1", "spmm_max_bwd_f256")):
         if key in name:
             return label
     return None
