@@ -77,7 +77,7 @@ CONFIGS = {
                  hbm_kernels=("spmm_max_fwd_f256", "spmm_max_bwd_f256")),
     "c3": dict(model="GAT", layer_sizes=[256] * 4, heads=[4] * 4, residuals=[False] * 4,
                metric="supervoxel-graphs/sec training, GAT 4 layers x 4 heads x 256, 15k-node graphs",
-               hbm_kernels=("gat_fwd",)),
+               hbm_kernels=("gat_fwd", "gat_bwd_edge", "gat_bwd_src")),
     "c5": dict(model="GSpool", layer_sizes=[256] * 7, heads=None, residuals=None,
                metric="volumes/sec inference: 7xSAGE-pool-256 forward + node-logit->voxel projection to 240^3",
                hbm_kernels=("project_rows",)),
@@ -250,6 +250,10 @@ def algorithmic_bytes(kernel, n_b, e_b, arg_bytes, heads=4, dim=256, n_vox=240 *
         return (4 * f + arg_bytes * f) * e_b + 4 * f * n_b + 4 * (2 * e_b + n_b + 1)
     if kernel == "gat_fwd":             # ft slice per (edge, head) + out + attn + el/er + CSR
         return 4 * heads * dim * e_b + 4 * heads * dim * n_b + 4 * heads * (3 * e_b + 2 * n_b) + 4 * (e_b + n_b + 1)
+    if kernel == "gat_bwd_edge":        # ft slice + gradient slice per (edge, head), attn in, ge out, scores, CSR
+        return 2 * 4 * heads * dim * e_b + 4 * heads * (2 * e_b + 3 * n_b) + 4 * (e_b + n_b + 1)
+    if kernel == "gat_bwd_src":         # gradient slice per (out-edge, head) + gft out + attn / ge per edge + out-CSR with positions
+        return 4 * heads * dim * e_b + 4 * heads * dim * n_b + 4 * heads * (2 * e_b + 2 * n_b) + 4 * (2 * e_b + n_b + 1)
     if kernel == "project_rows":        # int16 id in, 16-byte row out, per voxel
         return (2 + 16) * n_vox
     raise ValueError(kernel)
@@ -265,6 +269,11 @@ def compulsory_bytes(kernel, n_b, e_b, arg_bytes, heads=4, dim=256, n_vox=240 **
     if kernel == "gat_fwd":             # ft in, out, attn out, el/er in, bias, in-CSR
         return (2 * 4 * heads * dim * n_b + 4 * heads * e_b + 2 * 4 * heads * n_b + 4 * heads * dim
                 + 4 * (e_b + n_b + 1))
+    if kernel == "gat_bwd_edge":        # ft in, gradient in, attn in, ge out, el / er in, ger out, in-CSR
+        return 2 * 4 * heads * dim * n_b + 2 * 4 * heads * e_b + 3 * 4 * heads * n_b + 4 * (e_b + n_b + 1)
+    if kernel == "gat_bwd_src":         # gradient in, gft out, attn + ge in, gel out (+ ger, attn_l / attn_r), out-CSR + t_pos
+        return (2 * 4 * heads * dim * n_b + 2 * 4 * heads * e_b + 2 * 4 * heads * n_b + 2 * 4 * heads * dim
+                + 4 * (2 * e_b + n_b + 1))
     if kernel == "project_rows":        # ids in, rows out, the node table once
         return (2 + 16) * n_vox + 16 * n_b
     raise ValueError(kernel)
@@ -405,7 +414,8 @@ def main():
             if not (profiled and os.path.exists(path)):
                 return None, None
             with open(path) as fh:
-                return json.load(fh).get(key), "profiles/" + fname
+                value = json.load(fh).get(key)
+            return (value, "profiles/" + fname) if value is not None else (None, None)
 
         workloads = {
             "c2": "C2: 7xGraphSAGE-pool-256 (8 SAGEConv), fwd+weighted-CE+bwd+AdamW",

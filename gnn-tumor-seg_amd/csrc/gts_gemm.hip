@@ -1666,6 +1666,24 @@ extern "C" int32_t gts_set_option(int32_t option, int32_t value) {
   }
 }
 
+extern "C" int32_t gts_get_option(int32_t option) {
+  switch (option) {
+    case GTS_OPT_GEMM_TILE: return gts::g_fwd_variant;
+    case GTS_OPT_IGRAD_TILE: return gts::g_igrad_variant;
+    case GTS_OPT_SPMM_ROWS_PER_WAVE: return gts::g_spmm_seq;
+    case GTS_OPT_SPMM_STREAMING: return gts::g_spmm_nt;
+    case GTS_OPT_PROJECT_STREAMING: return gts::g_project_nt;
+    case GTS_OPT_WGRAD_TILE: return gts::g_wgrad_variant;
+    case GTS_OPT_GEMM_SCHED: return gts::g_gemm_sched;
+    case GTS_OPT_CLUSTER_STREAMING: return gts::g_cluster_nt;
+    case GTS_OPT_CLUSTER_KERNEL: return gts::g_cluster_kernel;
+    case GTS_OPT_CLUSTER_RING: return gts::g_cluster_ring;
+    case GTS_OPT_CLUSTER_PER_CU: return gts::g_cluster_per_cu;
+    case GTS_OPT_CLUSTER_CONSUMERS: return gts::g_cluster_consumers;
+    default: return INT32_MIN;
+  }
+}
+
 extern "C" int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const float* a1,
                                       const float* w1, const float* bias, float* out, int64_t m,
                                       int64_t n, int64_t k0, int64_t k1, int32_t relu,

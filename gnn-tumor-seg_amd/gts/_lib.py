@@ -58,6 +58,7 @@ SIGNATURES = {
     "gts_linear_bwd_weight_workspace": [_i64, _i64, _i64, _i32],
     "gts_linear_bwd_weight_f32": [_p, _p, _p, _p, _i32, _p, _i64, _i64, _i64, _i64, _p],
     "gts_set_option": [_i32, _i32],
+    "gts_get_option": [_i32],
     "gts_weighted_ce_workspace": [_i64],
     "gts_weighted_ce_f32": [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p],
 }

@@ -26,17 +26,23 @@ class row_count_invariant:
     Used where a batched forward must reproduce per-sample forwards bit for bit (GNN.evaluate)."""
 
     _depth = 0
+    _saved = -1      # the forward-tile option in force outside the outermost block (tools / GTS_OPTIONS may have set one)
+    _lock = __import__("threading").Lock()
 
     def __enter__(self):
-        if row_count_invariant._depth == 0:
-            check(_lib.load().gts_set_option(1, -2), "gts_set_option")
-        row_count_invariant._depth += 1
+        with row_count_invariant._lock:
+            if row_count_invariant._depth == 0:
+                lib = _lib.load()
+                row_count_invariant._saved = int(lib.gts_get_option(1))
+                check(lib.gts_set_option(1, -2), "gts_set_option")
+            row_count_invariant._depth += 1
         return self
 
     def __exit__(self, *exc):
-        row_count_invariant._depth -= 1
-        if row_count_invariant._depth == 0:
-            check(_lib.load().gts_set_option(1, -1), "gts_set_option")
+        with row_count_invariant._lock:
+            row_count_invariant._depth -= 1
+            if row_count_invariant._depth == 0:
+                check(_lib.load().gts_set_option(1, row_count_invariant._saved), "gts_set_option")
         return False
 
 
@@ -84,6 +90,12 @@ def _chk(*tensors):
         if t is not None and t.dtype != torch.float32:
             raise _lib.GtsError(f"gts GEMMs are fp32: got {t.dtype}")
     return require_device(*tensors)
+
+
+def _dense(*tensors):
+    """The kernels read every operand as a dense row-major matrix with ld = shape[1]: make it so (no copy when it
+    already is; a .t() view, a column slice or an expanded gradient is materialised here, never mis-read)."""
+    return tuple(t if t is None or t.is_contiguous() else t.contiguous() for t in tensors)
 
 
 def relu_bits_empty(m, n, device):
@@ -170,6 +182,7 @@ def linear_fwd_chain(a0, w0, a1, w1, bias, relu, w2, bias2, relu2, relu_bits=Non
     k0, k1 = a0.shape[1], a1.shape[1] if a1 is not None else 0
     if n % 4 or k0 % 4 or k1 % 4:
         raise _lib.GtsError("linear_fwd_chain needs widths that are multiples of 4")
+    a0, w0, a1, w1, bias, w2, bias2 = _dense(a0, w0, a1, w1, bias, w2, bias2)
     dev = _chk(a0, w0, a1, w1, bias, w2, bias2)
     _chk_bits(relu_bits, m, n, "relu_bits")
     out = torch.empty((m, n), dtype=torch.float32, device=dev)
@@ -200,6 +213,7 @@ def linear_bwd_input_chain_t(g0, w0t, g1, w1t, relu_mask, w2t, relu_bits=None):
     n0, n1 = g0.shape[1], g1.shape[1] if g1 is not None else 0
     if k % 4 or n0 % 4 or n1 % 4:
         raise _lib.GtsError("linear_bwd_input_chain_t needs widths that are multiples of 4")
+    g0, w0t, g1, w1t, relu_mask, w2t = _dense(g0, w0t, g1, w1t, relu_mask, w2t)
     dev = _chk(g0, w0t, g1, w1t, relu_mask, w2t)
     _chk_bits(relu_bits if relu_mask is not None else None, m, k, "relu_bits")
     relu_bits = relu_bits if relu_mask is not None else None
@@ -276,6 +290,7 @@ def linear_bwd_input_t(g0, w0t, g1=None, w1t=None, relu_mask=None, relu_bits=Non
     n0, n1 = g0.shape[1], g1.shape[1] if g1 is not None else 0
     if k % 4 or n0 % 4 or n1 % 4:
         raise _lib.GtsError("linear_bwd_input_t needs widths that are multiples of 4 (use linear_bwd_input)")
+    g0, w0t, g1, w1t, relu_mask = _dense(g0, w0t, g1, w1t, relu_mask)
     dev = _chk(g0, w0t, g1, w1t, relu_mask)
     relu_bits = relu_bits if relu_mask is not None else None
     _chk_bits(relu_bits, m, k, "relu_bits")

@@ -11,7 +11,9 @@ from ._lib import check, current_stream, ptr, require_device
 _ARG_DTYPE = {0: torch.uint8, 1: torch.uint8, 4: torch.int32}
 
 # bench.py installs callables here (kernel name -> wrapper) to bracket each launch of a kernel
-# with HIP events; empty in normal use.  Names: "spmm_max_fwd_f256", "spmm_max_bwd_f256", "gat_fwd",
+# with HIP events; empty in normal use.  Names: "spmm_max_fwd_f256", "spmm_max_bwd_f256", "gat_fwd", "gat_bwd_edge",
+# "gat_bwd_src" (the GAT kernels are bracketed for the HIDDEN-layer shape only: H * D >= 256; the 1-head classifier
+# launches move a hundredth of the bytes and would dilute the means), 
 # "project_rows".
 KERNEL_TIMERS = {}
 
@@ -197,9 +199,10 @@ def _gat_fwd(g, ft, el, er, slope, bias=None, residual=None, activation=0):
     out = torch.empty_like(ft)
     attn = torch.empty((g.number_of_edges(), h), dtype=torch.float32, device=ft.device)
     lib = _lib.load()
-    check(_timed("gat_fwd", lambda: lib.gts_gat_fwd_f32(
+    launch = lambda: lib.gts_gat_fwd_f32(      # noqa: E731
         ptr(d.indptr), ptr(d.indices), ptr(ft), ptr(el), ptr(er), float(slope), ptr(bias), ptr(residual),
-        activation, ptr(out), ptr(attn), n, h, dim, current_stream())), "gts_gat_fwd_f32")
+        activation, ptr(out), ptr(attn), n, h, dim, current_stream())
+    check(_timed("gat_fwd", launch) if h * dim >= 256 else launch(), "gts_gat_fwd_f32")
     return out, attn
 
 
@@ -218,14 +221,17 @@ def _gat_bwd(g, ft, el, er, attn, gout, slope, attn_l=None, attn_r=None):
     lib = _lib.load()
     ge = torch.empty_like(attn)
     ger = torch.empty_like(er)
-    check(lib.gts_gat_bwd_edge_f32(ptr(d.indptr), ptr(d.indices), ptr(ft), ptr(el), ptr(er), ptr(attn),
-                                   ptr(gout), float(slope), ptr(ge), ptr(ger), n, h, dim,
-                                   current_stream()), "gts_gat_bwd_edge_f32")
+    wide = h * dim >= 256
+    edge = lambda: lib.gts_gat_bwd_edge_f32(ptr(d.indptr), ptr(d.indices), ptr(ft), ptr(el), ptr(er), ptr(attn),   # noqa: E731
+                                            ptr(gout), float(slope), ptr(ge), ptr(ger), n, h, dim, current_stream())
+    check(_timed("gat_bwd_edge", edge) if wide else edge(), "gts_gat_bwd_edge_f32")
     gft = torch.empty_like(ft)
     gel = torch.empty_like(el)
-    check(lib.gts_gat_bwd_src_f32(ptr(d.t_indptr), ptr(d.t_indices), ptr(d.t_pos), ptr(attn), ptr(ge),
-                                  ptr(gout), ptr(attn_l), ptr(attn_r), ptr(ger) if attn_l is not None else None,
-                                  ptr(gft), ptr(gel), n, h, dim, current_stream()), "gts_gat_bwd_src_f32")
+    src = lambda: lib.gts_gat_bwd_src_f32(ptr(d.t_indptr), ptr(d.t_indices), ptr(d.t_pos), ptr(attn), ptr(ge),     # noqa: E731
+                                          ptr(gout), ptr(attn_l), ptr(attn_r),
+                                          ptr(ger) if attn_l is not None else None, ptr(gft), ptr(gel), n, h, dim,
+                                          current_stream())
+    check(_timed("gat_bwd_src", src) if wide else src(), "gts_gat_bwd_src_f32")
     return gft, gel, ger
 
 

@@ -235,8 +235,9 @@ class GNN:
         The forwards are BATCHED (`batch_size` samples per block-diagonal union, one launch chain
         instead of one per sample); rows of a block-diagonal batch never mix, and the GEMMs are pinned
         to the tile family whose rounding does not depend on the row count, so every logit — hence
-        every loss, count and Dice — is the double the one-sample-at-a-time route of the reference
-        produces (tests/test_gpu_cli.py).  Everything up to the Dice quotients stays on the GPU:
+        every loss, count and Dice — is identical for ANY `batch_size` of this method, `batch_size=1` (the
+        reference's one-sample-at-a-time route, under the same tile pin) included (tests/test_gpu_cli.py).
+        A forward OUTSIDE this method runs under the automatic tile choice and may round differently.  Everything up to the Dice quotients stays on the GPU:
         arg-max + projection is one K12 pass per sample, the node- and voxel-level label
         coincidences are counted by K15, and only the two 5x5 integer tables, the loss and the
         predicted volume (for the scipy distance transforms of HD95) travel to the host.

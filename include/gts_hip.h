@@ -349,6 +349,8 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
 #define GTS_OPT_CLUSTER_PER_CU 11    /* forms 0 / 2: persistent workgroups per CU (0 = automatic) */
 #define GTS_OPT_CLUSTER_CONSUMERS 12 /* form 0: waves per workgroup (default 8); form 2: consumer waves (0 = automatic) */
 int32_t gts_set_option(int32_t option, int32_t value);
+/* Current value of a knob (INT32_MIN for an unknown option): callers that change one temporarily put it back. */
+int32_t gts_get_option(int32_t option);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,9 @@ DGL rules encoded (each is also what the HIP path implements):
   R-mean  sum in in-edge order, then a true division by clamp(in_degree, 1).
   R-gcn   (sum + x[v]) / (in_degree + 1).
   R-lin   SAGEConv mean/gcn apply fc_neigh BEFORE aggregation when in_feats > out_feats.
-  R-bias  one shared `bias` parameter added after fc_self(h) + h_neigh (DGL >= 0.8 layout).
+  R-bias  ONE bias vector added after fc_self(h) + h_neigh.  Where DGL keeps it differs by version: a separate
+          `bias` parameter (0.8 - 0.9), `fc_self.bias` (>= 1.0), `fc_self.bias` + `fc_neigh.bias` (<= 0.6: their
+          sum); the function is the same, the product's loader folds whichever keys a checkpoint has.
   R-gat   e = leaky_relu(el[src] + er[dst]); a = softmax over the in-edges of each dst, per
           head (max-subtracted); out = sum_k a_k * ft[src_k]; + res_fc(h) ; + bias ; activation.
           Zero in-degree nodes raise (allow_zero_in_degree=False).

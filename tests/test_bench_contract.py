@@ -24,7 +24,12 @@ def test_algorithmic_bytes_match_design_doc():
     for kernel in ("spmm_max_fwd_f256", "spmm_max_bwd_f256", "gat_fwd"):
         assert bench.compulsory_bytes(kernel, n_b, e_b, 1) < bench.algorithmic_bytes(kernel, n_b, e_b, 1)
     assert bench.host_cores() >= 1
-    assert set(bench.CONFIGS) == {"c2", "c3", "c5"}
+    assert set(bench.CONFIGS) == {"c2", "c3", "c4", "c5", "real"}
+    assert bench.CONFIGS["c4"]["graphs_per_gpu"] == 8          # BASELINE.json: global batch 64 over 8 GPUs
+    real = bench.CONFIGS["real"]                               # /root/reference/utils/hyperparam_helpers.py:36-39, model/gnn_model.py:12
+    assert (real["in_feats"], real["layer_sizes"], real["graphs_per_gpu"]) == (20, [256] * 4, 6)
+    for kernel in ("gat_bwd_edge", "gat_bwd_src"):
+        assert bench.compulsory_bytes(kernel, n_b, e_b, 1) < bench.algorithmic_bytes(kernel, n_b, e_b, 1)
 
 
 @pytest.mark.gpu
@@ -80,3 +85,28 @@ def test_bench_gpus_2_starts_its_own_ranks(hip_lib):
     assert d["config"]["global_batch"] == 2 and d["config"]["parallelism"] == "dp2"
     assert d["all_reduce"]["payload_bytes"] == 4 * (1_252_888 + 2) and d["all_reduce"]["launches_timed"] == 2
     assert "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("config, kernels", [("c3", ["gat_fwd", "gat_bwd_edge", "gat_bwd_src"]),
+                                             ("c4", ["spmm_max_fwd_f256", "spmm_max_bwd_f256"]),
+                                             ("real", ["spmm_max_fwd_f256", "spmm_max_bwd_f256"])])
+def test_other_configs_keep_the_contract(hip_lib, config, kernels):
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--config", config, "--steps", "2",
+                          "--warmup", "1", "--blocks", "1", "--no-cpu-baseline"], capture_output=True, text=True,
+                         timeout=550, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert [h["kernel"] for h in d["roofline_hbm"]] == kernels
+    for h in d["roofline_hbm"]:
+        assert 0 < h["frac"] < 1 and (h["traffic"] is None) == (h["traffic_source"] is None)
+        assert (h["rocprof_avg_launch_us"] is None) == (h["rocprof_source"] is None)
+    if config == "c3":          # hidden layers only: four launches per step, the 1-head classifier is not averaged in
+        assert all(h["launches_timed"] == 2 * 4 for h in d["roofline_hbm"])
+    if config == "c4":
+        assert d["config"]["global_batch"] == 8 and d["config"]["nodes_per_batch"] == 120000
+        assert d["config"]["workload"].startswith("C4")
+    if config == "real":
+        assert d["config"]["global_batch"] == 6 and d["config"]["nodes_per_batch"] == 6 * 18 ** 3
+        assert d["config"]["resident_batches"]["value"] > 0 and d["config"]["host_enqueue_ms_per_step"] > 0

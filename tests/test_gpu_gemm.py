@@ -340,3 +340,33 @@ def test_relu_mask_as_bits_written_by_the_forward_and_read_by_the_input_gradient
         dense.relu_bits_empty(m, 96, DEV)
     with pytest.raises(dense._lib.GtsError, match="shapes do not match"):
         dense.linear_fwd(a0, w0, a1, w1, bias=b, relu=True, relu_bits=bits[:-1])
+
+
+def test_transposed_and_chained_entry_points_take_non_contiguous_operands():
+    """linear_bwd_input_t / linear_fwd_chain / linear_bwd_input_chain_t read operands as dense row-major matrices:
+    a .t() view, a column slice or an expanded gradient must be materialised by the wrapper, not mis-read."""
+    from gts import dense
+
+    torch.manual_seed(3)
+    m, k, n = 300, 64, 32
+    g_wide = torch.randn(m, 2 * n, device="cuda")
+    g0 = g_wide[:, ::2]                                  # column slice: stride 2
+    w = torch.randn(n, k, device="cuda")
+    wt_view = w.t().contiguous().t().t()                 # [k, n] ... a view chain that is contiguous
+    wt_strided = w.t()                                   # [k, n] with strides (1, k): NOT contiguous
+    want = dense.linear_bwd_input_t(g0.contiguous(), wt_view.contiguous())
+    assert torch.equal(dense.linear_bwd_input_t(g0, wt_strided), want)
+    expanded = torch.randn(m, 1, device="cuda").expand(m, n)     # stride 0 along the columns
+    assert torch.equal(dense.linear_bwd_input_t(expanded, wt_strided),
+                       dense.linear_bwd_input_t(expanded.contiguous(), wt_view.contiguous()))
+
+    a0 = torch.randn(k, m, device="cuda").t()            # [m, k] transposed view
+    w0, w2 = torch.randn(n, k, device="cuda"), torch.randn(16, n, device="cuda")
+    b0, b2 = torch.randn(n, device="cuda"), torch.randn(16, device="cuda")
+    out, out2 = dense.linear_fwd_chain(a0, w0, None, None, b0, True, w2.t().contiguous().t().contiguous(), b2, False)
+    ref1 = dense.linear_fwd(a0.contiguous(), w0, bias=b0, relu=True)
+    assert torch.equal(out, ref1) and torch.equal(out2, dense.linear_fwd(ref1, w2, bias=b2))
+
+    mask = torch.randn(k, m, device="cuda").t()          # non-contiguous ReLU source
+    gin, gin2 = dense.linear_bwd_input_chain_t(g0, wt_strided, None, None, mask, torch.randn(8, k, device="cuda"))
+    assert torch.equal(gin, dense.linear_bwd_input_t(g0.contiguous(), wt_view.contiguous(), relu_mask=mask.contiguous()))

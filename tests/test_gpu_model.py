@@ -196,6 +196,27 @@ def test_legacy_checkpoint_bias_folding_and_eval_mode():
     assert out.shape == (30, 4) and torch.isfinite(out).all()
 
 
+def test_checkpoint_with_only_fc_self_bias_loads_as_the_shared_bias():
+    """DGL >= 1.0 keeps the layer bias in `fc_self.bias` (fc_neigh has none, there is no separate `bias`): such a
+    checkpoint must load with that vector as the layer's bias — the same real-valued function (nn.py folds
+    whichever of fc_self.bias / fc_neigh.bias are present)."""
+    hp = HP(20, 4, [16], None, None)
+    ref = init_graph_net("GSpool", hp)
+    want = {k: torch.randn_like(v) for k, v in ref.state_dict().items()}
+    ref.load_state_dict(want)
+    newer = {(k[:-len("bias")] + "fc_self.bias" if k.endswith(".bias") and "fc_pool" not in k else k): v
+             for k, v in want.items()}
+    assert not any(k.endswith("layers.0.bias") or "fc_neigh.bias" in k for k in newer)
+    net = init_graph_net("GSpool", hp)
+    net.load_state_dict(newer)
+    for a, b in zip(net.state_dict().items(), ref.state_dict().items()):
+        assert a[0] == b[0] and torch.equal(a[1], b[1])
+    g = gts.Graph(*random_coo(30, 100, seed=1), 30).to(DEV)
+    x = torch.randn(30, 20, device=DEV)
+    with torch.no_grad():
+        assert torch.equal(net.to(DEV).eval()(g, x), ref.to(DEV).eval()(g, x))
+
+
 class _MemDataset(torch.utils.data.Dataset):
     """In-memory stand-in for ImageGraphDataset (same item layout)."""
 
