@@ -395,9 +395,9 @@ def main():
     last = blocks[-1][2]
     # one more block of the same K steps with HIP events around every launch of the kernels the
     # roofline objects describe (kept out of the blocks above: events cost a few us per launch)
-    timers.enabled = True
+    timers.enabled = ops.INSTRUMENTED = True
     instrumented = timed_block()[0]
-    timers.enabled = False
+    timers.enabled = ops.INSTRUMENTED = False
     # --config real: the same steps on two RESIDENT batches (every rank; the blocks fence collectively): what the host path costs
     resident = sorted(timed_block(resident_step)[0] for _ in range(3))[1] if args.config == "real" else None
     log(f"blocks: median {elapsed:.4f} s, min {times[0]:.4f}, max {times[-1]:.4f} for {args.steps} steps; "

@@ -146,6 +146,7 @@ class FlatGradSync:
         self.group = group
         self.flat = None
         self._scalars = None
+        self._sink = None                # gts.nn.GradSink over the same parameters (+ 2 floats), made on first use
 
     def flat_gradients(self):
         """The normalised gradients of the last step as one contiguous fp32 tensor (parameter
@@ -169,9 +170,13 @@ class FlatGradSync:
             num.backward()
             self._scalars = (den.detach().reshape(1), num.detach().reshape(1))
             return
-        from . import ops
+        from . import nn, ops
         grad, stats = ops.weighted_ce_numerator_grad(logits, labels, class_weights)
-        logits.backward(grad)                                   # d(numerator): the kernel's gradient as it is
+        if self._sink is None:
+            self._sink = nn.GradSink(self.params, extra=2)
+        self._sink.new_buffer()
+        with nn.grad_sink(self._sink):                          # a fused layer stack writes its gradients into the flat buffer
+            logits.backward(grad)                               # d(numerator): the kernel's gradient as it is
         self._scalars = (stats[1:2], stats[0:1])                # (denominator, numerator): views, no launch
 
     def empty_step(self, device=None):
@@ -179,6 +184,8 @@ class FlatGradSync:
         zero gradients, numerator and denominator, and still takes part in the collective."""
         for p in self.params:
             p.grad = None
+        if self._sink is not None:
+            self._sink.filled = False
         zeros = torch.zeros(2, dtype=torch.float32, device=device or self.params[0].device)
         self._scalars = (zeros[0:1], zeros[1:2])
 
@@ -188,8 +195,14 @@ class FlatGradSync:
         weighted-mean loss (0-dim tensor, no host sync)."""
         if self._scalars is None:
             raise RuntimeError("call weighted_ce_backward() first")
-        pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
-        self.flat = torch.cat(pieces + [t.to(pieces[0].dtype) for t in self._scalars])
+        if self._sink is not None and self._sink.filled:      # gradients are already in place: add the two scalars
+            self.flat = self._sink.flat
+            self.flat[self.n_grad:self.n_grad + 1].copy_(self._scalars[0])
+            self.flat[self.n_grad + 1:].copy_(self._scalars[1])
+            self._sink.filled = False
+        else:
+            pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+            self.flat = torch.cat(pieces + [t.to(pieces[0].dtype) for t in self._scalars])
         self._scalars = None
         _, w = world()
         if w > 1:

@@ -309,6 +309,138 @@ class _SagePoolStack(torch.autograd.Function):
         return (None, gx, None, *grads)
 
 
+# GTS_STACK_C=0 keeps the launch-by-launch Python loop of the fused stack (A/B runs; bench.py's instrumented block
+# uses it too, because HIP events are bracketed around single launches).
+STACK_IN_ONE_CALL = os.environ.get("GTS_STACK_C", "1") != "0"
+
+
+class GradSink:
+    """One flat fp32 buffer laid out like an optimizer's flat parameters (`params` in order, then `extra` spare
+    floats).  While a sink is active (`with grad_sink(sink)`), the fused pool stack writes its weight gradients
+    straight into `sink.flat` and hands autograd no per-parameter tensors — nothing is concatenated afterwards
+    (gts.optim.FlatAdamW.step(flat_grad=...), gts.dist.FlatGradSync).  `filled` says whether that happened."""
+
+    def __init__(self, params, extra=0):
+        self.params = list(params)
+        self.offsets, at = {}, 0
+        for p in self.params:
+            self.offsets[id(p)] = at
+            at += p.numel()
+        self.n, self.extra = at, int(extra)
+        self.flat, self.filled = None, False
+
+    def new_buffer(self):
+        self.flat = torch.empty(self.n + self.extra, dtype=torch.float32, device=self.params[0].device)
+        self.filled = False
+        return self.flat
+
+
+_active_sink = None
+
+
+class grad_sink:
+    def __init__(self, sink):
+        self.sink = sink
+
+    def __enter__(self):
+        global _active_sink
+        self.previous, _active_sink = _active_sink, self.sink
+        return self.sink
+
+    def __exit__(self, *exc):
+        global _active_sink
+        _active_sink = self.previous
+        return False
+
+
+def _stack_flags():
+    return (1 if CHAIN_LAYER_GEMMS else 0) | (2 if RELU_MASK_BITS else 0) | (4 if TRANSPOSED_IGRAD else 0)
+
+
+class _SagePoolStackCall(torch.autograd.Function):
+    """`_SagePoolStack` behind one C-ABI call each way (gts_sage_pool_stack_fwd_f32 / _bwd_f32: the same launches in
+    the same order, enqueued by the library; bit-identical, tests/test_gpu_stack.py).  Activations and winners live
+    in ONE arena tensor; gradients go into one flat buffer (the active GradSink's, or one of their own)."""
+
+    @staticmethod
+    def forward(ctx, g, x, need_bwd, *params):
+        import ctypes
+
+        from . import _lib
+        from ._lib import check, current_stream, ptr
+
+        lib = _lib.load()
+        x = x.contiguous()
+        n, n_layers = x.shape[0], len(params) // 5
+        widths = [x.shape[1]] + [params[5 * i + 2].shape[0] for i in range(n_layers)]
+        flags, ab = _stack_flags(), g.arg_bytes
+        d = g.dev()
+        c_widths = (ctypes.c_int64 * (n_layers + 1))(*widths)
+        offsets = (ctypes.c_int64 * (4 * n_layers + 2))()
+        total = lib.gts_sage_pool_stack_fwd_arena(n, c_widths, n_layers, 1 if need_bwd else 0, ab, flags, offsets)
+        if total < 0:
+            raise _lib.GtsError("gts_sage_pool_stack_fwd_arena rejected the stack's shape")
+        arena = torch.empty(max(int(total), 16), dtype=torch.uint8, device=x.device)
+        table = (ctypes.c_void_p * (5 * n_layers))(*[p.data_ptr() for p in params])
+        ds = ops._cluster_schedule(g, "in", n, 256, ab if need_bwd else 0) if 256 in widths[:-1] else None
+        h = ds.host if ds is not None else None
+        check(lib.gts_sage_pool_stack_fwd_f32(
+            ptr(d.indptr), ptr(d.indices), ptr(ds.packed) if ds else None, h.n_clusters if h else 0,
+            h.limits[0] if h else 0, h.limits[1] if h else 0, h.loc_words if h else 0, ptr(x), table, n, c_widths,
+            n_layers, 1 if need_bwd else 0, ab, flags, arena.data_ptr(), int(total), current_stream()),
+            "gts_sage_pool_stack_fwd_f32")
+        at = int(offsets[4 * (n_layers - 1) + 2])
+        out = arena[at:at + 4 * n * widths[-1]].view(torch.float32).view(n, widths[-1])
+        if need_bwd:
+            ctx.g, ctx.widths, ctx.flags, ctx.ab = g, widths, flags, ab
+            ctx.param_ids = [id(p) for p in params]
+            ctx.save_for_backward(x, arena, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        import ctypes
+
+        from . import _lib
+        from ._lib import check, current_stream, ptr
+
+        lib = _lib.load()
+        x, arena, *params = ctx.saved_tensors
+        g, widths, flags, ab = ctx.g, ctx.widths, ctx.flags, ctx.ab
+        n, n_layers = x.shape[0], len(params) // 5
+        gout = gout.contiguous()
+        d = g.dev()
+        sink = _active_sink
+        if sink is not None and not all(i in sink.offsets for i in ctx.param_ids):
+            sink = None
+        sizes = [p.numel() for p in params]
+        if sink is not None:
+            flat, starts = sink.flat, [sink.offsets[i] for i in ctx.param_ids]
+        else:
+            flat = torch.empty(sum(sizes), dtype=torch.float32, device=x.device)
+            starts = [0] * len(sizes)
+            for q in range(1, len(sizes)):
+                starts[q] = starts[q - 1] + sizes[q - 1]
+        base = flat.data_ptr()
+        grads = (ctypes.c_void_p * (5 * n_layers))(*[base + 4 * s for s in starts])
+        table = (ctypes.c_void_p * (5 * n_layers))(*[p.data_ptr() for p in params])
+        c_widths = (ctypes.c_int64 * (n_layers + 1))(*widths)
+        need = lib.gts_sage_pool_stack_bwd_scratch(n, c_widths, n_layers, flags)
+        scratch = torch.empty(max(int(need), 16), dtype=torch.uint8, device=x.device)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        ds = ops._cluster_schedule(g, "out", n, 256, ab) if 256 in widths[:-1] else None
+        h = ds.host if ds is not None else None
+        check(lib.gts_sage_pool_stack_bwd_f32(
+            ptr(d.t_indptr), ptr(d.t_indices), ptr(d.t_slot), ptr(ds.packed) if ds else None, h.n_clusters if h else 0,
+            h.limits[0] if h else 0, h.limits[1] if h else 0, h.loc_words if h else 0, ptr(gout), ptr(x), table, n,
+            c_widths, n_layers, ab, flags, arena.data_ptr(), grads, ptr(gx), scratch.data_ptr(), int(need),
+            current_stream()), "gts_sage_pool_stack_bwd_f32")
+        if sink is not None:
+            sink.filled = len(ctx.param_ids) == len(sink.params)
+            return (None, gx, None, *([None] * len(params)))
+        return (None, gx, None, *[flat[s:s + k].view_as(p) for s, k, p in zip(starts, sizes, params)])
+
+
 def sage_pool_stack(graph, features, layers):
     """Run `layers` (SAGEConv pool modules: ReLU on all but the last, no active dropout, bias on)
     as one fused autograd node.  Returns None when the stack does not have that shape, so the
@@ -325,7 +457,10 @@ def sage_pool_stack(graph, features, layers):
         params += [layer.fc_pool.weight, layer.fc_pool.bias, layer.fc_self.weight,
                    layer.fc_neigh.weight, layer.bias]
     need_bwd = torch.is_grad_enabled() and (features.requires_grad or any(p.requires_grad for p in params))
-    return _SagePoolStack.apply(graph, features, need_bwd, *params)
+    one_call = STACK_IN_ONE_CALL and not ops.INSTRUMENTED and not OVERLAP_WEIGHT_GRADS and features.shape[1] % 4 == 0 \
+        and all(p.shape[-1] % 4 == 0 and p.shape[0] % 4 == 0 and p.is_contiguous() for p in params) \
+        and features.dtype == torch.float32 and features.is_cuda
+    return (_SagePoolStackCall if one_call else _SagePoolStack).apply(graph, features, need_bwd, *params)
 
 
 class SAGEConv(nn.Module):

@@ -16,6 +16,9 @@ _ARG_DTYPE = {0: torch.uint8, 1: torch.uint8, 4: torch.int32}
 # launches move a hundredth of the bytes and would dilute the means), 
 # "project_rows".
 KERNEL_TIMERS = {}
+# True while bench.py runs its instrumented block: the fused layer stack then issues its launches one ctypes call at a
+# time (the route the timers bracket) instead of through the one-call entry points.
+INSTRUMENTED = False
 
 
 def _timed(name, launch):

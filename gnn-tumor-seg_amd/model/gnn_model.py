@@ -27,6 +27,7 @@ from data_processing.data_loader import ImageGraphDataset, minibatch_graphs
 from data_processing.graph_io import project_nodes_to_img
 from gts import dense as gdense
 from gts import dist as gdist
+from gts import nn as gnn
 from gts import ops as gops
 from gts.optim import FlatAdamW
 
@@ -93,6 +94,9 @@ class GNN:
         # fused HIP pass (gts_weighted_ce_f32)
         self.loss_fcn = lambda logits, labels: gops.weighted_cross_entropy(logits, labels, class_weights)
         self.grad_sync = None
+        # the fused layer stack writes its weight gradients straight into one flat buffer laid out like the optimizer's
+        # parameters (no per-parameter gradient tensors, nothing to concatenate before the AdamW launch)
+        self.grad_sink = gnn.GradSink(self.optimizer._params)
         self.global_batch_size = batch_size
         if train_dataset is None:
             self.train_loader = None
@@ -117,8 +121,13 @@ class GNN:
             grad, stats = gops.weighted_ce_numerator_grad(logits, labels, self.class_weights)
             grad.div_(stats[1])
             self.optimizer.zero_grad()
-            logits.backward(grad)
-            self.optimizer.step()
+            flat = self.grad_sink.new_buffer()
+            with gnn.grad_sink(self.grad_sink):
+                logits.backward(grad)
+            if self.grad_sink.filled:          # the whole network was one fused stack: its gradients are in `flat`
+                self.optimizer.step(flat_grad=flat)
+            else:
+                self.optimizer.step()
             return stats[2]
         self.grad_sync.zero_grad()
         self.grad_sync.weighted_ce_backward(logits, labels, self.class_weights)

@@ -314,6 +314,41 @@ int32_t gts_linear_bwd_weight_f32(const float* const* g, const float* const* a, 
                                   int64_t workspace_bytes, int64_t m, int64_t n, int64_t k,
                                   void* stream);
 
+/* ---- a whole stack of SAGEConv('pool') layers in one call each way -------------------------------
+ * Replaces the layer loop of GraphSage.forward (model/networks.py:32-36: `for layer in self.layers: h = layer(graph, h)`)
+ * over SAGEConv('pool') layers (model/networks.py:25,28,30: ReLU on all but the last, bias on) and its autograd.  HOST
+ * orchestration: the calls enqueue this library's own kernels (K1 / K2, K11 with their chained, transposed and batched
+ * forms) in a fixed order on `stream`; nothing is allocated.
+ *   widths[0] = in_feats, widths[i + 1] = output width of layer i (all multiples of 4); n_layers <= 64.
+ *   params[5 i .. 5 i + 4] = fc_pool.weight [w_i, w_i], fc_pool.bias [w_i], fc_self.weight [w_{i+1}, w_i],
+ *                            fc_neigh.weight [w_{i+1}, w_i], bias [w_{i+1}]                       (device pointers)
+ *   sched_*: optional cluster row schedule (gts_cluster_schedule) of the in-CSR (forward) / of the out-CSR tagged with
+ *            t_slot (backward); NULL = plain K1 / K2.  Used by the 256-wide layers when arg_bytes allows.
+ *   flags: 1 = chain consecutive GEMMs into one launch, 2 = record / read ReLU masks as bits, 4 = input gradients on
+ *          transposed weights (7 = what the layer-by-layer path does by default).
+ * Forward: everything it produces lives in `arena` (>= gts_sage_pool_stack_fwd_arena(...) bytes, which also reports the
+ * byte offsets: offsets[4 i .. 4 i + 3] = max-pooled features m_i [n, w_i], winners arg_i [n, w_i] (arg_bytes each; -1
+ * when not training), output out_i [n, w_{i+1}] (the next layer's input; the last one holds the logits), ReLU bits of out_i
+ * (-1 when absent); offsets[4 L], [4 L + 1] = two scratch buffers).  training = 0: no winners, no bits.
+ * Backward: `fwd_arena` is the arena of a training forward with the same arguments; grads[5 i .. 5 i + 4] receive the
+ * gradients of params[5 i .. 5 i + 4] (any caller-chosen destinations, e.g. slices of one flat buffer); gx [n, w_0]
+ * optional; scratch >= gts_sage_pool_stack_bwd_scratch(...) bytes. */
+int64_t gts_sage_pool_stack_fwd_arena(int64_t n_rows, const int64_t* widths, int32_t n_layers, int32_t training,
+                                      int32_t arg_bytes, int32_t flags, int64_t* offsets);
+int32_t gts_sage_pool_stack_fwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* sched_rec,
+                                    int64_t sched_clusters, int32_t sched_rows, int32_t sched_srcs,
+                                    int32_t sched_loc_words, const float* x, const float* const* params,
+                                    int64_t n_rows, const int64_t* widths, int32_t n_layers, int32_t training,
+                                    int32_t arg_bytes, int32_t flags, void* arena, int64_t arena_bytes, void* stream);
+int64_t gts_sage_pool_stack_bwd_scratch(int64_t n_rows, const int64_t* widths, int32_t n_layers, int32_t flags);
+int32_t gts_sage_pool_stack_bwd_f32(const int32_t* t_indptr, const int32_t* t_indices, const int32_t* t_slot,
+                                    const int32_t* sched_rec, int64_t sched_clusters, int32_t sched_rows,
+                                    int32_t sched_srcs, int32_t sched_loc_words, const float* gout, const float* x,
+                                    const float* const* params, int64_t n_rows, const int64_t* widths,
+                                    int32_t n_layers, int32_t arg_bytes, int32_t flags, const void* fwd_arena,
+                                    float* const* grads, float* gx, void* scratch, int64_t scratch_bytes,
+                                    void* stream);
+
 /* ---- class-weighted cross-entropy ----------------------------------------------------------
  * Replaces torch.nn.CrossEntropyLoss(weight=class_weights)(logits, labels) of the reference
  * harness (model/gnn_model.py:30,42) and, through grad_unscaled, its backward.
