@@ -22,6 +22,65 @@ import numpy as np
 import torch
 
 _I32_MAX = 2 ** 31 - 1
+import threading
+
+_uploads = threading.local()
+
+
+def host_staging_int32(n_words):
+    """(`n_words` int32 of host memory as a numpy array, the torch tensor that shares it): what batch() and the
+    schedule concatenation assemble in upload layout, so that it goes to the device in ONE copy without re-packing."""
+    a = np.empty(max(int(n_words), 4), dtype=np.int32)
+    return a, torch.from_numpy(a)
+
+
+class PinnedRing:
+    """A few page-locked slabs allocated ONCE (hipHostMalloc / hipHostFree cost milliseconds and synchronise the
+    device: never per batch) through which a loader thread stages its uploads: `upload(t, device)` copies the host
+    tensor into the current slab and enqueues an asynchronous host-to-device copy from there on the current stream.
+    `next_batch()` moves on to the next slab, first waiting for the copies that last read it."""
+
+    def __init__(self, slabs=3, nbytes=8 << 20):
+        self.slabs = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(slabs)]
+        self.events = [None] * slabs
+        self.cur, self.at = 0, 0
+
+    def next_batch(self):
+        self.events[self.cur] = torch.cuda.Event()
+        self.events[self.cur].record()
+        self.cur, self.at = (self.cur + 1) % len(self.slabs), 0
+        if self.events[self.cur] is not None:
+            self.events[self.cur].synchronize()
+
+    def upload(self, host, device):
+        nbytes = host.numel() * host.element_size()
+        start = (self.at + 255) & ~255
+        if start + nbytes > self.slabs[self.cur].numel():
+            if self.at == 0:      # larger than a whole slab: grow this one (rare; the old block is freed by torch when idle)
+                self.slabs[self.cur] = torch.empty(max(2 * nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
+                start = 0
+            else:                 # slab full: plain copy for the rest of this batch
+                return host.to(device)
+        stage = self.slabs[self.cur][start:start + nbytes].view(host.dtype).view(host.shape)
+        # a plain memcpy: torch's copy_ would start an OpenMP team in the loader thread (a new team per thread, spinning
+        # beside the main thread: 47 ms per batch measured), numpy copies in the calling thread
+        np.copyto(stage.numpy(), host.numpy())
+        self.at = start + nbytes
+        return stage.to(device, non_blocking=True)
+
+
+def uploads_through(ring):
+    """Route the uploads this THREAD makes from now on (graph CSRs, cluster schedules) through `ring` (None: plain copies)."""
+    _uploads.ring = ring
+
+
+def _upload(host_tensor, device):
+    ring = getattr(_uploads, "ring", None)
+    return ring.upload(host_tensor, device) if ring is not None else host_tensor.to(device)
+
+
+def _pad4(n):
+    return (int(n) + 3) & ~3
 
 
 class _DeviceCSR:
@@ -33,20 +92,25 @@ class _DeviceCSR:
     _INT_FIELDS = ("indptr", "indices", "t_indptr", "t_indices", "t_slot", "t_pos")
 
     def __init__(self, g, device):
-        deg = np.diff(g.indptr).astype(np.float32)
-        parts = [np.ascontiguousarray(getattr(g, name), dtype=np.int32) for name in self._INT_FIELDS]
-        parts += [np.maximum(deg, np.float32(1)).view(np.int32), (deg + np.float32(1)).view(np.int32)]
-        offsets, at = [], 0
-        for a in parts:                                  # every segment starts 16-byte aligned
-            offsets.append(at)
-            at += (a.size + 3) & ~3
-        host = np.empty(max(at, 4), dtype=np.int32)
-        for a, off in zip(parts, offsets):
-            host[off:off + a.size] = a
+        staged = getattr(g, "_staged", None)
+        if staged is not None:            # batch() assembled the arrays in upload layout already (page-locked memory)
+            host_tensor, offsets, sizes = staged
+        else:
+            deg = np.diff(g.indptr).astype(np.float32)
+            parts = [np.ascontiguousarray(getattr(g, name), dtype=np.int32) for name in self._INT_FIELDS]
+            parts += [np.maximum(deg, np.float32(1)).view(np.int32), (deg + np.float32(1)).view(np.int32)]
+            offsets, at = [], 0
+            for a in parts:                                  # every segment starts 16-byte aligned
+                offsets.append(at)
+                at += _pad4(a.size)
+            host, host_tensor = host_staging_int32(at)
+            for a, off in zip(parts, offsets):
+                host[off:off + a.size] = a
+            sizes = [a.size for a in parts]
         self.device = device
         self.schedules = {}               # 'in' / 'out' -> _DeviceSchedule (cluster row schedules, uploaded on first use)
-        self.packed = torch.from_numpy(host).to(device)
-        views = [self.packed[off:off + a.size] for a, off in zip(parts, offsets)]
+        self.packed = _upload(host_tensor, device)
+        views = [self.packed[off:off + size] for size, off in zip(sizes, offsets)]
         for name, v in zip(self._INT_FIELDS, views):
             setattr(self, name, v)
         self.deg_clamped = views[6].view(torch.float32)
@@ -66,7 +130,8 @@ class _DeviceSchedule:
 
     def __init__(self, sched, device):
         self.host = sched
-        self.packed = torch.from_numpy(sched.rec).to(device)
+        owner = sched.owner if sched.owner is not None else torch.from_numpy(sched.rec)
+        self.packed = _upload(owner, device).view(sched.rec.shape)
 
 
 class Graph:
@@ -288,16 +353,24 @@ def batch(graphs):
     eo32 = edge_off.astype(np.int32)
     n_total, e_total = int(node_off[-1]), int(edge_off[-1])
 
-    # one pass per array: every member slice is written (shifted) straight into its place
-    def cat_ptr(name):
-        out = np.empty(n_total + 1, dtype=np.int32)
+    # ONE host buffer in the layout _DeviceCSR uploads (indptr | indices | t_indptr | t_indices | t_slot | t_pos |
+    # max(deg, 1) | deg + 1 as fp32 bits; every segment 16-byte aligned); every member slice is written (shifted)
+    # straight into its place and the Graph's arrays are views of it: no second packing pass before the upload
+    seg_sizes = [n_total + 1, e_total, n_total + 1, e_total, e_total, e_total, n_total, n_total]
+    seg_at, at = [], 0
+    for size in seg_sizes:
+        seg_at.append(at)
+        at += _pad4(size)
+    host, owner = host_staging_int32(at)
+    seg = [host[o:o + size] for o, size in zip(seg_at, seg_sizes)]
+
+    def cat_ptr(name, out):
         for i, g in enumerate(graphs):
             np.add(getattr(g, name)[:-1], eo32[i], out=out[node_off[i]:node_off[i + 1]])
         out[n_total] = eo32[-1]
         return out
 
-    def cat_edges(name, shift):
-        out = np.empty(e_total, dtype=np.int32)
+    def cat_edges(name, shift, out):
         for i, g in enumerate(graphs):
             part = out[edge_off[i]:edge_off[i + 1]]
             if shift is None:
@@ -306,10 +379,14 @@ def batch(graphs):
                 np.add(getattr(g, name), shift[i], out=part)
         return out
 
-    prebuilt = (cat_ptr("indptr"), cat_edges("indices", no32), cat_ptr("t_indptr"), cat_edges("t_indices", no32),
-                cat_edges("t_slot", None), cat_edges("t_pos", eo32))
+    prebuilt = (cat_ptr("indptr", seg[0]), cat_edges("indices", no32, seg[1]), cat_ptr("t_indptr", seg[2]),
+                cat_edges("t_indices", no32, seg[3]), cat_edges("t_slot", None, seg[4]), cat_edges("t_pos", eo32, seg[5]))
+    deg = np.subtract(seg[0][1:], seg[0][:-1]).astype(np.float32)
+    np.maximum(deg, np.float32(1), out=seg[6].view(np.float32))
+    np.add(deg, np.float32(1), out=seg[7].view(np.float32))
     sizes = [s for g in graphs for s in g._batch_num_nodes]
     out = Graph(None, None, n_total, batch_num_nodes=sizes, _prebuilt=prebuilt, _members=(graphs, no32))
+    out._staged = (owner, seg_at, seg_sizes)
     common = set(graphs[0].ndata)
     for g in graphs[1:]:
         common &= set(g.ndata)

@@ -70,13 +70,15 @@ class _Layout:
 
 
 class ClusterSchedule:
-    __slots__ = ("limits", "tagged", "loc_words", "n_rows", "n_edges", "staged_rows", "rec")
+    __slots__ = ("limits", "tagged", "loc_words", "n_rows", "n_edges", "staged_rows", "rec", "owner")
 
-    def __init__(self, lim, tagged, loc_words, n_rows, n_edges, staged_rows, rec):
+    def __init__(self, lim, tagged, loc_words, n_rows, n_edges, staged_rows, rec, owner=None):
+        self.owner = owner               # the (page-locked) torch tensor `rec` is a view of, when concat() staged it for upload
         self.limits = tuple(int(v) for v in lim)
         self.tagged, self.loc_words = bool(tagged), int(loc_words)
         self.n_rows, self.n_edges, self.staged_rows = int(n_rows), int(n_edges), int(staged_rows)
-        self.rec = np.ascontiguousarray(rec, dtype=np.int32)
+        self.rec = rec if (isinstance(rec, np.ndarray) and rec.dtype == np.int32 and rec.flags.c_contiguous) \
+            else np.ascontiguousarray(rec, dtype=np.int32)
         assert self.rec.ndim == 2 and self.rec.shape[1] == self.layout.words
 
     @property
@@ -142,16 +144,20 @@ class ClusterSchedule:
         lim, tagged = parts[0].limits, parts[0].tagged
         if any(p.limits != lim or p.tagged != tagged for p in parts):
             raise ValueError("schedules built with different limits cannot be concatenated")
+        from .graph import host_staging_int32
+
         lw = max(p.loc_words for p in parts)
         parts = [p.with_loc_words(lw) for p in parts]
         lay = parts[0].layout
-        rec = np.concatenate([p.rec for p in parts])
-        at = 0
-        for i, p in enumerate(parts):
-            rec[at:at + p.n_clusters, lay.rows:lay.eoff] += np.int32(node_offsets[i])   # row ids and neighbour ids
-            at += p.n_clusters
+        counts = [p.n_clusters for p in parts]
+        host, owner = host_staging_int32(sum(counts) * lay.words)      # page-locked: one asynchronous upload
+        rec = host[:sum(counts) * lay.words].reshape(sum(counts), lay.words)
+        np.concatenate([p.rec for p in parts], out=rec)
+        shift = np.repeat(np.asarray(node_offsets[:len(parts)], dtype=np.int32), counts)
+        rec[:, lay.rows:lay.eoff] += shift[:, None]                   # row ids and neighbour ids of every cluster
         return ClusterSchedule(lim, tagged, lw, sum(p.n_rows for p in parts), sum(p.n_edges for p in parts),
-                               sum(p.staged_rows for p in parts), rec)
+                               sum(p.staged_rows for p in parts), rec,
+                               owner=owner[:rec.size] if owner is not None else None)
 
     def lds_bytes(self, kind):
         return int(_lib.load().gts_cluster_lds_bytes(self.limits[0], self.limits[1], self.loc_words, kind))

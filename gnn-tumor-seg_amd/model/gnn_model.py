@@ -29,6 +29,7 @@ from gts import dense as gdense
 from gts import dist as gdist
 from gts import nn as gnn
 from gts import ops as gops
+from gts.graph import PinnedRing, _upload, uploads_through
 from gts.optim import FlatAdamW
 
 from . import evaluation
@@ -94,6 +95,7 @@ class GNN:
         # fused HIP pass (gts_weighted_ce_f32)
         self.loss_fcn = lambda logits, labels: gops.weighted_cross_entropy(logits, labels, class_weights)
         self.grad_sync = None
+        self._pinned_ring = None
         # the fused layer stack writes its weight gradients straight into one flat buffer laid out like the optimizer's
         # parameters (no per-parameter gradient tensors, nothing to concatenate before the AdamW launch)
         self.grad_sink = gnn.GradSink(self.optimizer._params)
@@ -153,13 +155,25 @@ class GNN:
 
     def _to_device(self, graph, features, labels=None):
         graph = graph.to(self.device)
-        features = torch.as_tensor(np.asarray(features), dtype=torch.float32).to(self.device) \
-            if not isinstance(features, torch.Tensor) else features.to(self.device, torch.float32)
+
+        def up(t, dtype):      # in the prefetch thread: through its page-locked ring, asynchronously on the copy stream
+            t = torch.as_tensor(np.asarray(t), dtype=dtype) if not isinstance(t, torch.Tensor) else t.to(dtype)
+            return t.to(self.device) if t.is_cuda else _upload(t.contiguous(), self.device)
+        features = up(features, torch.float32)
         if labels is None:
             return graph, features
-        labels = torch.as_tensor(np.asarray(labels), dtype=torch.int64).to(self.device) \
-            if not isinstance(labels, torch.Tensor) else labels.to(self.device, torch.int64)
-        return graph, features, labels
+        return graph, features, up(labels, torch.int64)
+
+    def _schedules_wanted(self, n_rows):
+        """Cluster row schedules ('in' / 'out') the training step of this network will ask the graph for: the
+        prefetch thread builds and uploads them with the batch instead of leaving that to the first kernel call."""
+        from gts import schedule
+        from gts.nn import SAGEConv
+
+        if not schedule.ENABLED or not any(isinstance(m, SAGEConv) and m._aggre_type == "pool" and m._in_src_feats == 256
+                                           for m in self.net.modules()):
+            return ()
+        return ("out", "in") if n_rows >= schedule.MIN_ROWS_FORWARD else ("out",)
 
     def _device_batches(self):
         """The loader's batches, already on the GPU, prepared one step ahead: a worker thread
@@ -180,6 +194,9 @@ class GNN:
         def produce():
             try:
                 torch.cuda.set_device(device_index)
+                if self._pinned_ring is None:          # page-locked staging slabs: allocated once per GNN, reused every batch
+                    self._pinned_ring = PinnedRing()
+                uploads_through(self._pinned_ring)
                 for item in self.train_loader:
                     if stop.is_set():
                         return
@@ -190,8 +207,11 @@ class GNN:
                     with torch.cuda.stream(copy_stream):
                         batch = self._to_device(graph, feats, labels)
                         batch[0].dev()                     # CSR upload belongs to the copy as well
+                        for which in self._schedules_wanted(batch[0].n):
+                            batch[0].dev_schedule(which)   # ... and so do the cluster row schedules the step will read
                         ready = torch.cuda.Event()
                         ready.record(copy_stream)
+                        self._pinned_ring.next_batch()
                     slots.put((batch, ready))
                 slots.put(None)
             except BaseException as exc:                   # noqa: BLE001 - re-raised in the consumer
