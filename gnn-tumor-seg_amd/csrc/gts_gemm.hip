@@ -640,10 +640,10 @@ struct PanelStage {   // one GEMM of the panel kernel: c[rows of the panel, rb] 
 // most of its code (the generic kernel is ~100 KB of instructions, more than the instruction cache).
 enum : int { kEpiBias = 1, kEpiRelu = 2, kEpiMaskBits = 4, kEpiBitsOut = 16, kEpiRuntime = 256, kEpiAbsent = -1 };
 
-template <int WM, int WN, int DEPTH, int F = kEpiRuntime>
+template <int WM, int WN, int DEPTH, int F = kEpiRuntime, int ROWS = kR240>
 __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int sched, int m0, int n0, int row_end) {
   constexpr bool G = (F & kEpiRuntime) != 0;
-  constexpr int WTM = kR240 / WM, WTN = kC240 / WN, TM = WTM / 16, TN = WTN / 16;
+  constexpr int WTM = ROWS / WM, WTN = kC240 / WN, TM = WTM / 16, TN = WTN / 16;
   constexpr int R = DEPTH + 1;                     // register sets of fragments
   constexpr int kLd = WTN + 4, kStage = 16 * kLd;  // per-wave epilogue patch [16][WTN + 4]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
@@ -833,14 +833,14 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
   }
 }
 
-template <int WM, int WN, int DEPTH, class Probe = NoProbe, int F1 = kEpiRuntime, int F2 = kEpiRuntime>
+template <int WM, int WN, int DEPTH, class Probe = NoProbe, int F1 = kEpiRuntime, int F2 = kEpiRuntime, int ROWS = kR240>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_kernel(const GemmArgs p) {
   constexpr int WTN = kC240 / WN;
-  static_assert((kR240 / WM) % 16 == 0 && WTN % 16 == 0 && WTN % 4 == 0 && (WM * WN) % 4 == 0, "wave tiles are whole 16x16 tiles");
-  // epilogue patches [16][WTN + 4] per wave, then the waves' mask words (kR240 / WM / 16 * 16 of 8 bytes each)
-  __shared__ __attribute__((aligned(16))) float lds[WM * WN * 16 * (WTN + 4) + WM * WN * (kR240 / WM) * 2];
-  const int m0 = blockIdx.x * kR240, n0 = blockIdx.y * kC240;
-  const int row_end = min(p.ra, m0 + kR240);
+  static_assert((ROWS / WM) % 16 == 0 && WTN % 16 == 0 && WTN % 4 == 0 && (WM * WN) % 4 == 0, "wave tiles are whole 16x16 tiles");
+  // epilogue patches [16][WTN + 4] per wave, then the waves' mask words (ROWS / WM / 16 * 16 of 8 bytes each)
+  __shared__ __attribute__((aligned(16))) float lds[WM * WN * 16 * (WTN + 4) + WM * WN * (ROWS / WM) * 2];
+  const int m0 = blockIdx.x * ROWS, n0 = blockIdx.y * kC240;
+  const int row_end = min(p.ra, m0 + ROWS);
   Probe::mark(0);
   Probe::mark(1);
   PanelStage s0{};
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
   s0.ra = p.ra, s0.rb = p.rb, s0.ldc = p.ldc, s0.relu = p.relu, s0.c = p.c, s0.bias = p.bias, s0.mask = p.mask;
   s0.sc_l = p.sc_l, s0.sc_r = p.sc_r, s0.sc_el = p.sc_el, s0.sc_er = p.sc_er;
   s0.bits_out = p.bits_out, s0.bits_in = p.bits_in;
-  panel_stage<WM, WN, DEPTH, F1>(s0, lds, p.sched, m0, n0, row_end);
+  panel_stage<WM, WN, DEPTH, F1, ROWS>(s0, lds, p.sched, m0, n0, row_end);
   Probe::mark(2);
   // With c2 set a second GEMM follows in the same launch: the rows this workgroup has just stored are
   // its A operand (the next layer's fc_pool behind fc_self + fc_neigh; the next input gradient behind
@@ -865,14 +865,14 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
     s1.lda[0] = s1.lda[1] = p.ldc, s1.ldb[0] = s1.ldb[1] = p.ldb2;
     s1.kseg[0] = p.rb, s1.kseg[1] = 0;
     s1.ra = p.ra, s1.rb = p.rb2, s1.ldc = p.ldc2, s1.relu = p.relu2, s1.c = p.c2, s1.bias = p.bias2, s1.mask = nullptr;
-    panel_stage<WM, WN, DEPTH, F2 == kEpiAbsent ? kEpiRuntime : F2>(s1, lds, p.sched, m0, 0, row_end);
+    panel_stage<WM, WN, DEPTH, F2 == kEpiAbsent ? kEpiRuntime : F2, ROWS>(s1, lds, p.sched, m0, 0, row_end);
   }
   Probe::mark(3);
 }
 
-template <int WM, int WN, int DEPTH, class Probe = NoProbe>
+template <int WM, int WN, int DEPTH, class Probe = NoProbe, int ROWS = kR240>
 int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
-  dim3 grid((p.ra + kR240 - 1) / kR240, (p.rb + kC240 - 1) / kC240, 1);
+  dim3 grid((p.ra + ROWS - 1) / ROWS, (p.rb + kC240 - 1) / kC240, 1);
   GemmArgs q = p;
   q.sched = g_gemm_sched;
   if constexpr (WM == 3 && WN == 4 && DEPTH == 1 && std::is_same<Probe, NoProbe>::value) {
@@ -883,19 +883,19 @@ int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
     const int f2 = p.c2 == nullptr ? kEpiAbsent : (p.bias2 ? kEpiBias : 0) | (p.relu2 ? kEpiRelu : 0);
     constexpr int kFwd = kEpiBias | kEpiRelu;
     if (whole && f1 == (kFwd | kEpiBitsOut) && f2 == kFwd) {          // fc_self + fc_neigh, then the next fc_pool (training)
-      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kFwd | kEpiBitsOut, kFwd><<<grid, 768, 0, st>>>(q);
+      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kFwd | kEpiBitsOut, kFwd, ROWS><<<grid, 768, 0, st>>>(q);
       return launch_status();
     }
     if (whole && f1 == kEpiMaskBits && f2 == 0) {                     // a layer's input gradient, then g @ W_neigh below
-      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kEpiMaskBits, 0><<<grid, 768, 0, st>>>(q);
+      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kEpiMaskBits, 0, ROWS><<<grid, 768, 0, st>>>(q);
       return launch_status();
     }
     if (whole && f1 == 0 && f2 == kEpiAbsent) {                       // a plain product (g @ W_neigh of the top layer)
-      gemm_panel_direct_kernel<3, 4, 1, NoProbe, 0, kEpiAbsent><<<grid, 768, 0, st>>>(q);
+      gemm_panel_direct_kernel<3, 4, 1, NoProbe, 0, kEpiAbsent, ROWS><<<grid, 768, 0, st>>>(q);
       return launch_status();
     }
   }
-  gemm_panel_direct_kernel<WM, WN, DEPTH, Probe><<<grid, 64 * WM * WN, 0, st>>>(q);
+  gemm_panel_direct_kernel<WM, WN, DEPTH, Probe, kEpiRuntime, kEpiRuntime, ROWS><<<grid, 64 * WM * WN, 0, st>>>(q);
   return launch_status();
 }
 
@@ -1353,6 +1353,24 @@ int launch_tiles(const GemmArgs& p, int grid_y_mult, int splits, hipStream_t st)
   return launch_status();
 }
 
+// Height of the row panels the direct-to-fragment kernel (variant 10) cuts `rows` into.  One workgroup per CU per
+// round, so a CU walks rounds x height rows: 240 rows suit 60 000 (250 panels) and 120 000 rows (500 = two rounds),
+// but 35 000 rows (the reference's real batches: 6 graphs of ~6k nodes) are 146 panels of 240 on 256 CUs; 144-row
+// panels (243 of them) fill the chip.  Candidates 240 / 192 / 144 (5 / 4 / 3 MFMA row blocks per wave); the taller
+// panel wins ties (fewer loads per MFMA).  The result of a row does not depend on the height (same reduction order).
+int g_panel_rows = 0;   // 0 = automatic; 240 / 192 / 144 force one (tools/tune_gemm.py)
+inline int panel_rows_for(int64_t rows, int64_t col_blocks) {
+  if (g_panel_rows == 240 || g_panel_rows == 192 || g_panel_rows == 144) return g_panel_rows;
+  int best = kR240;
+  int64_t best_cost = -1;
+  for (int h : {240, 192, 144}) {
+    const int64_t panels = (rows + h - 1) / h * col_blocks;
+    const int64_t cost = (panels + 255) / 256 * h;
+    if (best_cost < 0 || cost < best_cost) best = h, best_cost = cost;
+  }
+  return best;
+}
+
 template <bool AKC, bool BKC>
 int pick_plain_variant(const GemmArgs& p) {
   int variant = BKC ? g_fwd_variant : g_igrad_variant;
@@ -1364,9 +1382,12 @@ int pick_plain_variant(const GemmArgs& p) {
     variant = big_tiles >= 192 ? 8 : 3;
     if constexpr (AKC && BKC) {
       // one workgroup per CU, in rounds of 256: rows a CU walks with 256-row tiles vs 240-row panels
-      const int64_t panels = static_cast<int64_t>((p.ra + kR240 - 1) / kR240) * cols;
-      const int64_t rows256 = (big_tiles + 255) / 256 * 256, rows240 = (panels + 255) / 256 * kR240;
-      if (variant == 8 && rows240 < rows256 && !row_count_invariant) variant = 10;
+      const int h = panel_rows_for(p.ra, cols);
+      const int64_t panels = static_cast<int64_t>((p.ra + h - 1) / h) * cols;
+      const int64_t rows256 = (big_tiles + 255) / 256 * 256, rows_panel = (panels + 255) / 256 * h;
+      if (variant == 8 && rows_panel < rows256 && !row_count_invariant) variant = 10;
+      // shorter operands: panels that fill at least 3/4 of the CUs in their one round beat two half-empty rounds of 64 x 256 tiles
+      if (variant == 3 && panels >= 192 && panels <= 256 && !row_count_invariant) variant = 10;
     }
   }
   return variant;
@@ -1559,7 +1580,13 @@ int launch_plain(const GemmArgs& p, hipStream_t st) {
       return launch_plain<true, true>(next, st);
     }
     // the panel kernels keep the mask bits themselves (written / read in their epilogue)
-    if (variant == 10) return launch_panel_direct<3, 4, 1>(p, st);
+    if (variant == 10) {
+      switch (panel_rows_for(p.ra, (p.rb + kC240 - 1) / kC240)) {
+        case 144: return launch_panel_direct<3, 4, 1, NoProbe, 144>(p, st);
+        case 192: return launch_panel_direct<3, 4, 1, NoProbe, 192>(p, st);
+        default: return launch_panel_direct<3, 4, 1>(p, st);
+      }
+    }
     if (variant == 11) return launch_panel_direct<1, 4, 1>(p, st);
     if (variant == 12) return launch_panel_direct<1, 4, 2>(p, st);
   }
@@ -1658,6 +1685,7 @@ extern "C" int32_t gts_set_option(int32_t option, int32_t value) {
     case GTS_OPT_WGRAD_TILE: gts::g_wgrad_variant = value; return GTS_OK;
     case GTS_OPT_GEMM_SCHED: gts::g_gemm_sched = value; return GTS_OK;
     case GTS_OPT_CLUSTER_STREAMING: gts::g_cluster_nt = value; return GTS_OK;
+    case GTS_OPT_PANEL_ROWS: gts::g_panel_rows = value; return GTS_OK;
     case GTS_OPT_CLUSTER_KERNEL: gts::g_cluster_kernel = value; return GTS_OK;
     case GTS_OPT_CLUSTER_RING: gts::g_cluster_ring = value; return GTS_OK;
     case GTS_OPT_CLUSTER_PER_CU: gts::g_cluster_per_cu = value; return GTS_OK;
@@ -1676,6 +1704,7 @@ extern "C" int32_t gts_get_option(int32_t option) {
     case GTS_OPT_WGRAD_TILE: return gts::g_wgrad_variant;
     case GTS_OPT_GEMM_SCHED: return gts::g_gemm_sched;
     case GTS_OPT_CLUSTER_STREAMING: return gts::g_cluster_nt;
+    case GTS_OPT_PANEL_ROWS: return gts::g_panel_rows;
     case GTS_OPT_CLUSTER_KERNEL: return gts::g_cluster_kernel;
     case GTS_OPT_CLUSTER_RING: return gts::g_cluster_ring;
     case GTS_OPT_CLUSTER_PER_CU: return gts::g_cluster_per_cu;
