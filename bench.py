@@ -407,7 +407,9 @@ def main():
 
     if rank == 0:
         arg_b = batches[0][0].arg_bytes
-        profiled = args.graphs_per_gpu == 4 and args.graph_kind == "lattice"   # what the committed profiles ran
+        # the committed profiles ran the lattice workload at 4, 8 and 32 graphs per GPU (C2 / C3 models)
+        tag = {4: "", 8: "b8_", 32: "b32_"}.get(args.graphs_per_gpu)
+        profiled = tag is not None and args.graph_kind == "lattice" and args.config in ("c2", "c3", "c4", "c5")
 
         def from_profile(fname, key):
             path = os.path.join(REPO, "profiles", fname)
@@ -461,8 +463,10 @@ def main():
             secs = sum(v["total_ms"] for v in kinds.values()) * 1e-3
             tf = flops / secs / 1e12
             result["roofline"] = {
-                "bound": "mfma", "kernel": "gts::gemm_kernel (K11: every forward / input-gradient / "
-                                           "weight-gradient launch of the step)",
+                "bound": "mfma",
+                "kernel": "K11, every forward / input-gradient / weight-gradient launch of the step: "
+                          "gts::gemm_panel_direct_kernel (16x16x4 MFMA row panels: the chained layer GEMMs, ~58 % of a C2 step) "
+                          "and gts::gemm_kernel<256,256,...> (32x32x2 MFMA split-reduction weight gradients, ~26 %)",
                 "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                 "flops_per_step": flops / args.steps, "gemm_ms_per_step": round(1e3 * secs / args.steps, 4),
@@ -481,8 +485,8 @@ def main():
             us = 1e3 * s["total_ms"] / s["launches"]
             need = compulsory_bytes(name, n_b, e_b, arg_b)
             alg = algorithmic_bytes(name, n_b, e_b, arg_b)
-            traffic, source = from_profile("pmc_traffic.json", name + "_bytes_per_launch")
-            rocprof_us, rsource = from_profile("rocprof_kernel_avg.json", name + "_avg_us")
+            traffic, source = from_profile(f"pmc_traffic{'_' + tag[:-1] if tag else ''}.json", name + "_bytes_per_launch")
+            rocprof_us, rsource = from_profile("rocprof_kernel_avg.json", (tag or "") + name + "_avg_us")
             gbs = need / (us * 1e-6) / 1e9
             hbm.append({"bound": "hbm", "kernel": name, "model": "compulsory bytes: every input/output array once",
                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -353,6 +353,24 @@ class grad_sink:
         return False
 
 
+_stack_tables = {}   # (parameter storage addresses) -> (pointer table, widths) as ctypes arrays, built once per network
+
+
+def _stack_table(params, in_feats):
+    import ctypes
+
+    key = (in_feats, *[p.data_ptr() for p in params])
+    hit = _stack_tables.get(key)
+    if hit is None:
+        n_layers = len(params) // 5
+        widths = [in_feats] + [params[5 * i + 2].shape[0] for i in range(n_layers)]
+        hit = ((ctypes.c_void_p * (5 * n_layers))(*key[1:]), (ctypes.c_int64 * (n_layers + 1))(*widths), widths)
+        if len(_stack_tables) > 64:
+            _stack_tables.clear()
+        _stack_tables[key] = hit
+    return hit
+
+
 def _stack_flags():
     return (1 if CHAIN_LAYER_GEMMS else 0) | (2 if RELU_MASK_BITS else 0) | (4 if TRANSPOSED_IGRAD else 0)
 
@@ -372,16 +390,14 @@ class _SagePoolStackCall(torch.autograd.Function):
         lib = _lib.load()
         x = x.contiguous()
         n, n_layers = x.shape[0], len(params) // 5
-        widths = [x.shape[1]] + [params[5 * i + 2].shape[0] for i in range(n_layers)]
+        table, c_widths, widths = _stack_table(params, x.shape[1])
         flags, ab = _stack_flags(), g.arg_bytes
         d = g.dev()
-        c_widths = (ctypes.c_int64 * (n_layers + 1))(*widths)
         offsets = (ctypes.c_int64 * (4 * n_layers + 2))()
         total = lib.gts_sage_pool_stack_fwd_arena(n, c_widths, n_layers, 1 if need_bwd else 0, ab, flags, offsets)
         if total < 0:
             raise _lib.GtsError("gts_sage_pool_stack_fwd_arena rejected the stack's shape")
         arena = torch.empty(max(int(total), 16), dtype=torch.uint8, device=x.device)
-        table = (ctypes.c_void_p * (5 * n_layers))(*[p.data_ptr() for p in params])
         ds = ops._cluster_schedule(g, "in", n, 256, ab if need_bwd else 0) if 256 in widths[:-1] else None
         h = ds.host if ds is not None else None
         check(lib.gts_sage_pool_stack_fwd_f32(
@@ -423,8 +439,7 @@ class _SagePoolStackCall(torch.autograd.Function):
                 starts[q] = starts[q - 1] + sizes[q - 1]
         base = flat.data_ptr()
         grads = (ctypes.c_void_p * (5 * n_layers))(*[base + 4 * s for s in starts])
-        table = (ctypes.c_void_p * (5 * n_layers))(*[p.data_ptr() for p in params])
-        c_widths = (ctypes.c_int64 * (n_layers + 1))(*widths)
+        table, c_widths, _ = _stack_table(params, x.shape[1])
         need = lib.gts_sage_pool_stack_bwd_scratch(n, c_widths, n_layers, flags)
         scratch = torch.empty(max(int(need), 16), dtype=torch.uint8, device=x.device)
         gx = torch.empty_like(x) if ctx.needs_input_grad[1] else None

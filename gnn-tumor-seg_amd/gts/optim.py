@@ -37,9 +37,11 @@ class FlatAdamW(torch.optim.Optimizer):
         self.steps = 0
 
     def _still_flat(self):
+        """Every parameter is still the slice of the flat buffer it was made (re-allocations such as net.to(...) would
+        break that).  `Tensor._version`-free and cheap: storage addresses only."""
         base, off = self.flat_param.data_ptr(), 0
         for p, n in zip(self._params, self._sizes):
-            if p.data_ptr() != base + 4 * off or not p.is_contiguous():
+            if p.data_ptr() != base + 4 * off:
                 return False
             off += n
         return True

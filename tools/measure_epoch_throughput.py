@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """End-to-end epoch throughput of GNN.run_epoch on in-memory samples (collate + upload + step),
 with and without the batch-prefetch thread, next to bench.py's resident-batch figure.
-  python tools/measure_epoch_throughput.py [--samples 48] [--batch 4] [--nodes-kind lattice]"""
+  python tools/measure_epoch_throughput.py [--config c2|real] [--samples 48] [--batch N] [--graph-kind lattice]
+--config real: the reference's own workload (in_feats 20, layer_sizes [256]*4, 6 graphs of ~6k nodes per step)."""
 import argparse
 import contextlib
 import json
@@ -21,7 +22,10 @@ from model.gnn_model import GNN  # noqa: E402
 
 
 class MemDataset(torch.utils.data.Dataset):
-    def __init__(self, n, kind):
+    def __init__(self, n, kind, cfg):
+        if "in_feats" in cfg:      # the reference's real shape
+            self.items = [bench.real_sample(i, cfg["in_feats"]) for i in range(n)]
+            return
         self.items = [synth.make_sample(i, kind=kind, in_feats=bench.IN_FEATS) for i in range(n)]
         self.items = [(f"s{i}", g, f.astype("float64"), y) for i, (_, g, f, y) in enumerate(self.items)]
 
@@ -35,11 +39,13 @@ class MemDataset(torch.utils.data.Dataset):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=48)
-    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--graph-kind", default="lattice")
+    ap.add_argument("--config", default="c2", choices=["c2", "real"])
     args = ap.parse_args()
-    data = MemDataset(args.samples, args.graph_kind)
-    cfg = bench.CONFIGS["c2"]
+    cfg = bench.CONFIGS[args.config]
+    args.batch = args.batch or cfg.get("graphs_per_gpu", 4)
+    data = MemDataset(args.samples, args.graph_kind, cfg)
     for prefetch in (False, True, False, True):
         torch.manual_seed(0)
         with contextlib.redirect_stdout(sys.stderr):
@@ -51,7 +57,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         steps = len(model.train_loader)
-        print(json.dumps({"prefetch": prefetch, "graphs_per_s": round(steps * args.batch / dt, 1),
+        print(json.dumps({"config": args.config, "batch": args.batch, "prefetch": prefetch, "graphs_per_s": round(steps * args.batch / dt, 1),
                           "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "epoch_loss": float(loss)}),
               flush=True)
 

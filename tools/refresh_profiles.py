@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import summarize_rocprof  # noqa: E402
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 src, dst = f"gpurun_out/{tag}", "profiles"
 
 
@@ -23,12 +23,13 @@ def last_json_line(path):
     return lines[-1]
 
 
-for name in ("c2", "c3", "c5", "c2_b8", "c2_b32"):
+for name in ("c2", "c3", "c5", "c2_b8", "c2_b32", "real"):
     with open(f"{dst}/{rnd}_bench_{name}.json", "w") as fh:
         fh.write(last_json_line(f"{src}/bench_{name}.json") + "\n")
-for name in ("pmc_traffic.json", "pmc_traffic_b32.json"):
+for name in ("pmc_traffic.json", "pmc_traffic_b8.json", "pmc_traffic_b32.json"):
     shutil.copy(f"{src}/{name}", f"{dst}/{name}")
 shutil.copy(f"{src}/aux_kernels.jsonl", f"{dst}/{rnd}_aux_kernels.jsonl")
+shutil.copy(f"{src}/epoch_throughput.jsonl", f"{dst}/{rnd}_epoch_throughput.jsonl")
 
 
 def stats(prof_dir, out_stem, steps, title):
@@ -51,22 +52,38 @@ def mean_us(rows, needle):
 c2 = stats("prof", f"{rnd}_bench", 65, f"Round {rnd[1:]}: bench.py --steps 20 --warmup 5 --blocks 2 (C2; 5 warm-up + 2 timed blocks + 1 "
            "instrumented block = 65 steps)")
 c3 = stats("prof_c3", f"{rnd}_bench_c3", 12, f"Round {rnd[1:]}: bench.py --config c3 --steps 5 --warmup 2 --blocks 1 (GAT 4x4x256; 2 + 5 + 5 = 12 steps)")
+b8 = stats("prof_b8", f"{rnd}_bench_c2_b8", 12, f"Round {rnd[1:]}: bench.py --config c4 --steps 5 --warmup 2 --blocks 1 (8 graphs per GPU; 2 + 5 + 5 = 12 steps)")
 b32 = stats("prof_b32", f"{rnd}_bench_c2_b32", 7, f"Round {rnd[1:]}: bench.py --graphs-per-gpu 32 --steps 3 --warmup 1 --blocks 1 (1 + 3 + 3 = 7 steps)")
+stats("prof_real", f"{rnd}_bench_real", 105, f"Round {rnd[1:]}: bench.py --config real --steps 20 --warmup 5 --blocks 1 (5 + 20 + 20 fresh-batch steps + 3 x 20 resident)")
 stats("prof_aux", f"{rnd}_aux", 1, f"Round {rnd[1:]}: tools/measure_aux_kernels.py (streaming kernels around the network)")
+K1 = (("spmm_cluster_stream_kernel<false, 1",), ("spmm_max_fwd_kernel<4, 64, 1>",))     # clustered form first, plain form otherwise
+K2 = (("spmm_cluster_stream_kernel<true, 1",), ("spmm_max_bwd_kernel<4, 64, 1>",))
+
+
+def first_mean(rows, needles):
+    """(mean us, calls, which form ran) of the first kernel name pattern that occurs."""
+    for needle in needles:
+        if any(all(s_ in n for s_ in needle) for n in rows):
+            us, calls = mean_us(rows, needle)
+            return us, calls, "clustered" if "cluster" in needle[0] else "plain"
+    return None, 0, None
+
+
 panel, panel_calls = mean_us(c2, ("gemm_panel_direct_kernel<3, 4, 1",))
-avg = {
-    "source": f"profiles/{rnd}_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 5 --blocks 2 "
-              "--no-cpu-baseline`, kernel-only durations)",
-    "spmm_max_fwd_f256_avg_us": mean_us(c2, ("spmm_max_fwd_kernel<4, 64, 1>",))[0],
-    "spmm_max_bwd_f256_avg_us": mean_us(c2, ("spmm_max_bwd_kernel<4, 64, 1>",))[0],
-    "gemm_panel_direct_avg_us": panel,
-    "gemm_panel_direct_calls": panel_calls,
-    "gemm_wgrad_256x256_avg_us": mean_us(c2, ("gemm_kernel<256, 256, 4, 4, false, false, true",))[0],
-    "b32_source": f"profiles/{rnd}_bench_c2_b32_kernel_stats.csv (--graphs-per-gpu 32)",
-    "b32_spmm_max_fwd_f256_avg_us": mean_us(b32, ("spmm_max_fwd_kernel<4, 64, 1>",))[0],
-    "b32_spmm_max_bwd_f256_avg_us": mean_us(b32, ("spmm_max_bwd_kernel<4, 64, 1>",))[0],
-    "c3_source": f"profiles/{rnd}_bench_c3_kernel_stats.csv (--config c3)",
-    "gat_fwd_avg_us": mean_us(c3, ("gat_fwd_kernel<4, 64>",))[0],
-}
+avg = {"source": f"profiles/{rnd}_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 5 --blocks 2 "
+                 "--no-cpu-baseline`, kernel-only durations)",
+       "gemm_panel_direct_avg_us": panel, "gemm_panel_direct_calls": panel_calls,
+       "gemm_wgrad_256x256_avg_us": mean_us(c2, ("gemm_kernel<256, 256, 4, 4, false, false, true",))[0]}
+for tag, rows, label in (("", c2, "C2"), ("b8_", b8, "--config c4 (8 graphs per GPU)"), ("b32_", b32, "--graphs-per-gpu 32")):
+    for key, needles in (("spmm_max_fwd_f256", K1), ("spmm_max_bwd_f256", K2)):
+        us, calls, form = first_mean(rows, needles)
+        avg[f"{tag}{key}_avg_us"], avg[f"{tag}{key}_form"] = us, form
+    if tag:
+        avg[f"{tag}source"] = f"profiles/{rnd}_bench_c2_{tag[:-1]}_kernel_stats.csv ({label})"
+avg["c3_source"] = f"profiles/{rnd}_bench_c3_kernel_stats.csv (--config c3)"
+for key, needle in (("gat_fwd", ("gat_fwd_kernel<4, 64>",)), ("gat_bwd_edge", ("gat_bwd_edge_kernel<4",)),
+                    ("gat_bwd_src", ("gat_bwd_src_kernel<4",))):
+    hits = [n for n in c3 if needle[0] in n]
+    avg[f"{key}_avg_us"] = mean_us(c3, needle)[0] if hits else None
 json.dump(avg, open(f"{dst}/rocprof_kernel_avg.json", "w"), indent=1)
 print(json.dumps(avg, indent=1))

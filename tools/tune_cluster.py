@@ -43,8 +43,8 @@ for b in [int(a) for a in sys.argv[1:]] or [4, 8, 32]:
           f"slot={s_in.lds_bytes(0)}/{s_out.lds_bytes(1)} B", flush=True)
     # (label, enabled, {option: value}): 9 = kernel form, 10 = ring slots, 11 = workgroups per CU, 12 = consumer waves
     variants = [("plain", False, {}), ("unit-wg", True, {9: 1}), ("stream 8w x2", True, {}),
-                ("stream 4w x2", True, {12: 4}), ("stream 6w x2", True, {12: 6}), ("stream 8w x1", True, {11: 1}),
-                ("ring=3 cons=5", True, {9: 2, 10: 3, 12: 5})]
+                ("stream 8w x3", True, {11: 3}), ("stream 8w x4", True, {11: 4}), ("stream 6w x4", True, {11: 4, 12: 6}),
+                ("stream 4w x2", True, {12: 4}), ("stream 8w x1", True, {11: 1}), ("ring=3 cons=5", True, {9: 2, 10: 3, 12: 5})]
     for label, enabled, options in variants:
         schedule.ENABLED = enabled
         for k, v in options.items():
