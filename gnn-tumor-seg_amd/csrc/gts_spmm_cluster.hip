@@ -293,7 +293,10 @@ __device__ __forceinline__ void gather_winner_halves(const Dma& dma, int part, u
 // WHATIF != 0 only in the timing experiments of tools/diag (wrong results): 1 = no row gathers, 2 = no reduction and
 // no stores, 3 = no stores, 4 = stores without the reduction (K1).
 template <bool BWD, int ARGB, int WHATIF = 0>
-__global__ __launch_bounds__(512) void spmm_cluster_stream_kernel(const ClusterArgs a) {
+// Two workgroups per CU: 16 waves each for K1 (<= 64 registers), 12 for K2 (its 68 registers: 6 waves per SIMD).  With 8 waves
+// the reduction of a unit is latency-bound (lattice, 8 graphs: 67.6 / 72.2 us against 63.9 / 67.8; k-NN graphs of mean
+// degree 7 - 10: 78 - 144 us against 65 - 96, profiles/r03_cluster_other_graphs.log).
+__global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(const ClusterArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -532,7 +535,7 @@ inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_
     // persistent streaming form: three record slots + two images per workgroup, as many workgroups per CU as fit (<= 2)
     const int64_t wg_lds = 3LL * 1024 * ((a.layout.words + 255) / 256) + 2LL * (p.slot_bytes - p.image_off);
     if (wg_lds > kMaxLds || a.layout.words > 512) return GTS_ERR_SHAPE;
-    const int waves = g_cluster_consumers > 0 ? std::min(8, g_cluster_consumers) : 8;
+    const int waves = g_cluster_consumers > 0 ? std::min(16, g_cluster_consumers) : (BWD ? 12 : 16);
     if (a.max_srcs > 64 * waves) return GTS_ERR_SHAPE;
     const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g_cluster_per_cu > 0 ? g_cluster_per_cu : 2, kMaxLds / wg_lds)));
     int64_t grid = static_cast<int64_t>(device_cus()) * per_cu;

@@ -285,8 +285,10 @@ class Graph:
                 else:
                     sched = _schedule.ClusterSchedule.build(self.t_indptr, self.t_indices, self.indptr, self.indices,
                                                             self.t_slot, lim)
-                if sched is not None and not sched.worthwhile():
-                    sched = None
+                if sched is not None:
+                    degrees = np.diff(self.indptr if which == "in" else self.t_indptr)
+                    if not sched.worthwhile(int(degrees.max()) if degrees.size else 0):
+                        sched = None
             self._sched[which] = sched
         return self._sched[which]
 

@@ -38,6 +38,14 @@ ENABLED = os.environ.get("GTS_CLUSTER_SPMM", "1") != "0"
 # the clustered kernel stages them (in the training step at 60 000 rows: 30 us against 34 us; at 120 000 rows: 86 us
 # against 72 us).  K2 is faster clustered at every size measured (60 000 rows: 46 -> 38 us).
 MIN_ROWS_FORWARD = int(os.environ.get("GTS_CLUSTER_MIN_ROWS_FWD", "100000"))
+# Where the clustered kernels stop paying (profiles/r03_cluster_other_graphs.log: k-nearest-neighbour graphs of random points,
+# 8 x 15 000 nodes, against the plain kernels).  Their reduction costs per edge what the plain kernel's does, but runs in 24 - 32
+# waves per CU that move in step with their unit's barrier, so denser graphs become compute-bound earlier:
+#   K1: faster up to a mean in-degree of about 11 (degree 7.2: 65 vs 88 us; 10.4: 96 vs 107; 13.8: 135 vs 121);
+#   K2: faster only while every row fits ONE 8-edge chunk (lattice, degree <= 8: 68 vs 86 us; degree 7.2 with rows of up to 15
+#       edges: 101 vs 90).
+MAX_MEAN_DEGREE_FORWARD = float(os.environ.get("GTS_CLUSTER_MAX_MEAN_DEGREE_FWD", "11"))
+MAX_DEGREE_BACKWARD = int(os.environ.get("GTS_CLUSTER_MAX_DEGREE_BWD", "8"))
 
 
 def limits(which):
@@ -89,9 +97,14 @@ class ClusterSchedule:
     def layout(self):
         return _Layout(self.limits[0], self.limits[1], self.loc_words, self.tagged)
 
-    def worthwhile(self):
-        """Neighbour rows staged per launch against the rows the plain kernel fetches (one per edge)."""
-        return self.n_edges > 0 and self.staged_rows <= WORTHWHILE * self.n_edges
+    def worthwhile(self, max_degree=None):
+        """Does the clustered kernel beat the plain one on this graph?  It must stage clearly fewer neighbour rows than
+        the plain kernel fetches (one per edge), and the graph must be sparse enough for its reduction (see above)."""
+        if self.n_edges == 0 or self.staged_rows > WORTHWHILE * self.n_edges:
+            return False
+        if self.tagged:      # K2
+            return max_degree is None or max_degree <= MAX_DEGREE_BACKWARD
+        return self.n_edges <= MAX_MEAN_DEGREE_FORWARD * self.n_rows
 
     def with_loc_words(self, loc_words):
         """The same schedule with the per-edge sections re-packed to `loc_words` words (>= what the edges need)."""

@@ -13,7 +13,25 @@ from tests.helpers import random_coo
 
 @pytest.fixture(scope="module", autouse=True)
 def _lib(hip_lib):
-    return hip_lib
+    old = schedule.MAX_MEAN_DEGREE_FORWARD, schedule.MAX_DEGREE_BACKWARD
+    schedule.MAX_MEAN_DEGREE_FORWARD, schedule.MAX_DEGREE_BACKWARD = 1e9, 10 ** 9     # density rules: tested on their own below
+    yield hip_lib
+    schedule.MAX_MEAN_DEGREE_FORWARD, schedule.MAX_DEGREE_BACKWARD = old
+
+
+def test_density_rules_pick_the_kernel_per_graph():
+    """Speed policy, not semantics: dense or irregular graphs keep the plain kernels (profiles/r03_cluster_other_graphs.log)."""
+    old = schedule.MAX_MEAN_DEGREE_FORWARD, schedule.MAX_DEGREE_BACKWARD
+    schedule.MAX_MEAN_DEGREE_FORWARD, schedule.MAX_DEGREE_BACKWARD = 11.0, 8
+    try:
+        lattice = synth.lattice_graph((10, 10, 10), self_loops=True)            # degree <= 7: both clustered
+        assert lattice.cluster_schedule("in") is not None and lattice.cluster_schedule("out") is not None
+        sparse = synth.geometric_graph(n=3000, k=6, seed=1)                     # mean degree ~7, rows of up to ~15 edges
+        assert sparse.cluster_schedule("in") is not None and sparse.cluster_schedule("out") is None
+        dense = synth.geometric_graph(n=3000, k=16, seed=1)                     # mean degree ~19
+        assert dense.cluster_schedule("in") is None and dense.cluster_schedule("out") is None
+    finally:
+        schedule.MAX_MEAN_DEGREE_FORWARD, schedule.MAX_DEGREE_BACKWARD = old
 
 
 def _check_cover(g, which, sched):

@@ -18,10 +18,11 @@ DEV = "cuda"
 @pytest.fixture(scope="module", autouse=True)
 def _lib(hip_lib):
     assert torch.cuda.is_available(), "GPU tests need an MI355X"
-    old = schedule.MIN_ROWS_FORWARD
-    schedule.MIN_ROWS_FORWARD = 0          # the size rule of K1 is a speed choice: here every size takes the clustered kernel
+    old = schedule.MIN_ROWS_FORWARD, schedule.MAX_MEAN_DEGREE_FORWARD, schedule.MAX_DEGREE_BACKWARD
+    # the size and density rules are speed choices: here every graph with a schedule takes the clustered kernels
+    schedule.MIN_ROWS_FORWARD, schedule.MAX_MEAN_DEGREE_FORWARD, schedule.MAX_DEGREE_BACKWARD = 0, 1e9, 10 ** 9
     yield hip_lib
-    schedule.MIN_ROWS_FORWARD = old
+    schedule.MIN_ROWS_FORWARD, schedule.MAX_MEAN_DEGREE_FORWARD, schedule.MAX_DEGREE_BACKWARD = old
 
 
 def _plain(fn):
