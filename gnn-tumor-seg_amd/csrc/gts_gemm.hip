@@ -857,6 +857,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
   // this one) — one launch, one cold start and one output burst less per layer, and the operand
   // comes back out of this CU's own L2 slice.
   if (F2 != kEpiAbsent && ((F2 & kEpiRuntime) == 0 || p.c2 != nullptr)) {
+    // Stage 2 re-reads rows of c that OTHER waves of this workgroup stored.  Ordering: every wave's vmcnt(0), then the
+    // workgroup barrier.  That is enough because the workgroup runs on one CU whose vector L1 all its waves share
+    // (the default, non-tgsplit execution mode) and the stores are ordinary ones (the launcher never combines
+    // non-temporal stores, sched bit 2, with a second stage).
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's rows of c are in memory ...
     __threadfence_block();
     __syncthreads();                       // ... and so are every other wave's, before any is read back
@@ -875,6 +879,7 @@ int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
   dim3 grid((p.ra + ROWS - 1) / ROWS, (p.rb + kC240 - 1) / kC240, 1);
   GemmArgs q = p;
   q.sched = g_gemm_sched;
+  if (p.c2 != nullptr) q.sched &= ~2;   // chained launches read their own output back through L1 / L2: ordinary stores only
   if constexpr (WM == 3 && WN == 4 && DEPTH == 1 && std::is_same<Probe, NoProbe>::value) {
     // the launches of the SAGE-pool layer stack at its 256-wide layers: compile-time epilogues
     const bool whole = p.rb % kC240 == 0 && p.ldc % 4 == 0 && p.sc_l == nullptr && (p.mask == nullptr || p.bits_in != nullptr) &&
@@ -888,6 +893,14 @@ int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
     }
     if (whole && f1 == kEpiMaskBits && f2 == 0) {                     // a layer's input gradient, then g @ W_neigh below
       gemm_panel_direct_kernel<3, 4, 1, NoProbe, kEpiMaskBits, 0, ROWS><<<grid, 768, 0, st>>>(q);
+      return launch_status();
+    }
+    if (whole && f1 == kFwd && f2 == kFwd) {                          // the same pair without mask bits (no-grad forward: inference, evaluate)
+      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kFwd, kFwd, ROWS><<<grid, 768, 0, st>>>(q);
+      return launch_status();
+    }
+    if (whole && f1 == kFwd && f2 == kEpiAbsent) {                    // one biased ReLU layer on its own (fc_pool of the first wide layer)
+      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kFwd, kEpiAbsent, ROWS><<<grid, 768, 0, st>>>(q);
       return launch_status();
     }
     if (whole && f1 == 0 && f2 == kEpiAbsent) {                       // a plain product (g @ W_neigh of the top layer)
