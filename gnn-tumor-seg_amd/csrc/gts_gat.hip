@@ -14,6 +14,17 @@ namespace {
 
 __device__ __forceinline__ float leaky(float x, float slope) { return x > 0.0f ? x : x * slope; }
 
+// Which (node, head) row the w-th unit of work is.  Head-major (all nodes of head 0, then head 1, ...): the rows a
+// workgroup's neighbours gather then lie 1 KiB apart per node instead of H KiB, so the window of nodes whose slices
+// the XCD's L2 holds is H times longer — the +-x neighbours of a supervoxel lattice stay inside it, as they do for K1.
+// Node-major (w = row index) is kept for A/B runs.  The arithmetic of a row does not depend on the walk.
+__device__ __forceinline__ int walk_row(int w, int n_rows, int heads, int head_major) {
+  if (w < 0 || !head_major) return w;
+  const int n_nodes = n_rows / heads;
+  const int h = w / n_nodes;
+  return (w - h * n_nodes) * heads + h;
+}
+
 // sum over the LPR lanes that share a row (xor butterfly stays inside the aligned group)
 template <int LPR>
 __device__ __forceinline__ float group_sum(float x) {
@@ -61,10 +72,10 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
     const float* __restrict__ ft, const float* __restrict__ el, const float* __restrict__ er,
     float slope, float* __restrict__ out, float* __restrict__ attn,
     const float* __restrict__ bias, const float* __restrict__ residual, int act, int n_rows,
-    int heads, int dim, int seq) {
+    int heads, int dim, int seq, int head_major) {
   const int gl = (threadIdx.x & (kWave - 1)) % LPR;
   for (int s = 0; s < seq; ++s) {
-    const int r = owned_row<LPR>(s, seq, n_rows);
+    const int r = walk_row(owned_row<LPR>(s, seq, n_rows), n_rows, heads, head_major);
     if (r < 0) continue;
     const int v = r / heads, h = r - v * heads;
     const int beg = indptr[v], end = indptr[v + 1];
@@ -190,10 +201,10 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const float* __restrict__ ft, const float* __restrict__ el, const float* __restrict__ er,
     const float* __restrict__ attn, const float* __restrict__ gout, float slope,
-    float* __restrict__ ge, float* __restrict__ ger, int n_rows, int heads, int dim, int seq) {
+    float* __restrict__ ge, float* __restrict__ ger, int n_rows, int heads, int dim, int seq, int head_major) {
   const int gl = (threadIdx.x & (kWave - 1)) % LPR;
   for (int s = 0; s < seq; ++s) {
-    const int r = owned_row<LPR>(s, seq, n_rows);
+    const int r = walk_row(owned_row<LPR>(s, seq, n_rows), n_rows, heads, head_major);
     // all lanes of a group share r, so the shuffles below are convergent per group;
     // groups past the end still take part in the wave-wide shuffle with zeros.
     const bool live = r >= 0;
@@ -330,10 +341,10 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_kernel(
     const int32_t* __restrict__ t_pos, const float* __restrict__ attn,
     const float* __restrict__ ge, const float* __restrict__ gout, float* __restrict__ gft,
     float* __restrict__ gel, const float* __restrict__ attn_l, const float* __restrict__ attn_r,
-    const float* __restrict__ ger, int n_rows, int heads, int dim, int seq) {
+    const float* __restrict__ ger, int n_rows, int heads, int dim, int seq, int head_major) {
   const int gl = (threadIdx.x & (kWave - 1)) % LPR;
   for (int s = 0; s < seq; ++s) {
-    const int r = owned_row<LPR>(s, seq, n_rows);
+    const int r = walk_row(owned_row<LPR>(s, seq, n_rows), n_rows, heads, head_major);
     if (r < 0) continue;
     const int u = r / heads, h = r - u * heads;
     const int beg = t_indptr[u], end = t_indptr[u + 1];
@@ -449,8 +460,9 @@ extern "C" int32_t gts_gat_fwd_f32(const int32_t* indptr, const int32_t* indices
   const Geometry g = make_geometry(n * heads, dim);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nr = static_cast<int>(n * heads), nh = static_cast<int>(heads), nd = static_cast<int>(dim);
+  const int hm = g_gat_walk;
   GTS_DISPATCH_GEOM(g, {
-    gat_fwd_kernel<VEC, LPR><<<g.grid, kBlock, 0, st>>>(indptr, indices, ft, el, er, negative_slope, out, attn, bias, residual, activation, nr, nh, nd, g.seq);
+    gat_fwd_kernel<VEC, LPR><<<g.grid, kBlock, 0, st>>>(indptr, indices, ft, el, er, negative_slope, out, attn, bias, residual, activation, nr, nh, nd, g.seq, hm);
   })
   return launch_status();
 }
@@ -467,8 +479,9 @@ extern "C" int32_t gts_gat_bwd_edge_f32(const int32_t* indptr, const int32_t* in
   const Geometry g = make_geometry(n * heads, dim);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nr = static_cast<int>(n * heads), nh = static_cast<int>(heads), nd = static_cast<int>(dim);
+  const int hm = g_gat_walk;
   GTS_DISPATCH_GEOM(g, {
-    gat_bwd_edge_kernel<VEC, LPR><<<g.grid, kBlock, 0, st>>>(indptr, indices, ft, el, er, attn, gout, negative_slope, ge, ger, nr, nh, nd, g.seq);
+    gat_bwd_edge_kernel<VEC, LPR><<<g.grid, kBlock, 0, st>>>(indptr, indices, ft, el, er, attn, gout, negative_slope, ge, ger, nr, nh, nd, g.seq, hm);
   })
   return launch_status();
 }
@@ -488,8 +501,9 @@ extern "C" int32_t gts_gat_bwd_src_f32(const int32_t* t_indptr, const int32_t* t
   const Geometry g = make_geometry(n * heads, dim);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nr = static_cast<int>(n * heads), nh = static_cast<int>(heads), nd = static_cast<int>(dim);
+  const int hm = g_gat_walk;
   GTS_DISPATCH_GEOM(g, {
-    gat_bwd_src_kernel<VEC, LPR><<<g.grid, kBlock, 0, st>>>(t_indptr, t_indices, t_pos, attn, ge, gout, gft, gel, attn_l, attn_r, ger, nr, nh, nd, g.seq);
+    gat_bwd_src_kernel<VEC, LPR><<<g.grid, kBlock, 0, st>>>(t_indptr, t_indices, t_pos, attn, ge, gout, gft, gel, attn_l, attn_r, ger, nr, nh, nd, g.seq, hm);
   })
   return launch_status();
 }

@@ -1699,6 +1699,7 @@ extern "C" int32_t gts_set_option(int32_t option, int32_t value) {
     case GTS_OPT_GEMM_SCHED: gts::g_gemm_sched = value; return GTS_OK;
     case GTS_OPT_CLUSTER_STREAMING: gts::g_cluster_nt = value; return GTS_OK;
     case GTS_OPT_PANEL_ROWS: gts::g_panel_rows = value; return GTS_OK;
+    case GTS_OPT_GAT_WALK: gts::g_gat_walk = value; return GTS_OK;
     case GTS_OPT_CLUSTER_KERNEL: gts::g_cluster_kernel = value; return GTS_OK;
     case GTS_OPT_CLUSTER_RING: gts::g_cluster_ring = value; return GTS_OK;
     case GTS_OPT_CLUSTER_PER_CU: gts::g_cluster_per_cu = value; return GTS_OK;
@@ -1718,6 +1719,7 @@ extern "C" int32_t gts_get_option(int32_t option) {
     case GTS_OPT_GEMM_SCHED: return gts::g_gemm_sched;
     case GTS_OPT_CLUSTER_STREAMING: return gts::g_cluster_nt;
     case GTS_OPT_PANEL_ROWS: return gts::g_panel_rows;
+    case GTS_OPT_GAT_WALK: return gts::g_gat_walk;
     case GTS_OPT_CLUSTER_KERNEL: return gts::g_cluster_kernel;
     case GTS_OPT_CLUSTER_RING: return gts::g_cluster_ring;
     case GTS_OPT_CLUSTER_PER_CU: return gts::g_cluster_per_cu;

@@ -378,6 +378,7 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
                                 4 = the direct-to-fragment kernels keep every epilogue switch a run-time argument (the generic
                                     instantiation) instead of the compile-time epilogues of the layer-stack launches (A/B runs) */
 #define GTS_OPT_CLUSTER_STREAMING 8 /* clustered K1 / K2: bit 0 = non-temporal stores of out / gx; -1 = per-kernel default */
+#define GTS_OPT_GAT_WALK 14          /* K5-K8: 1 = walk the (node, head) rows head-major (default), 0 = node-major */
 #define GTS_OPT_PANEL_ROWS 13        /* K11 direct-to-fragment panels: rows per panel, 0 = automatic among 240 / 192 / 144 */
 #define GTS_OPT_CLUSTER_KERNEL 9     /* clustered K1 / K2: 0 = persistent streaming workgroups (default), 1 = one workgroup per unit,
                                         2 = persistent workgroups with loader waves feeding a ring of slots to consumer waves */
