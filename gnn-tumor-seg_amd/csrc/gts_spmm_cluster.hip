@@ -79,20 +79,13 @@ struct ClusterArgs {
 
 __device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // wait until at most n of this wave's vector-memory operations (the youngest) are outstanding
+#define GTS_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
 __device__ __forceinline__ void wait_vm_all_but(int n) {
   switch (n) {
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    GTS_VMCNT_CASE(1) GTS_VMCNT_CASE(2) GTS_VMCNT_CASE(3) GTS_VMCNT_CASE(4) GTS_VMCNT_CASE(5) GTS_VMCNT_CASE(6)
+    GTS_VMCNT_CASE(7) GTS_VMCNT_CASE(8) GTS_VMCNT_CASE(9) GTS_VMCNT_CASE(10) GTS_VMCNT_CASE(11) GTS_VMCNT_CASE(12)
+    GTS_VMCNT_CASE(13) GTS_VMCNT_CASE(14) GTS_VMCNT_CASE(15) GTS_VMCNT_CASE(16) GTS_VMCNT_CASE(17) GTS_VMCNT_CASE(18)
+    GTS_VMCNT_CASE(19) GTS_VMCNT_CASE(20) GTS_VMCNT_CASE(21) GTS_VMCNT_CASE(22) GTS_VMCNT_CASE(23) GTS_VMCNT_CASE(24)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // waiting for more is always correct
   }
 }
@@ -309,7 +302,10 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
   const int words = a.layout.words;
   const int pieces = (words + 255) / 256;   // a record arrives as one or two whole 1 KiB LDS-DMA pieces (lanes past its end deliver zeros)
   const int rec_bytes = 1024 * pieces, image_bytes = a.slot_bytes - a.image_off;
-  unsigned char* images = lds + 3 * rec_bytes;
+  // gathers run `depth` units ahead of the reduction: depth + 1 images, depth + 2 record slots (the record of the unit whose
+  // gathers are issued next is fetched one iteration before that)
+  const int depth = a.ring, n_images = depth + 1, n_recs = depth + 2;
+  unsigned char* images = lds + n_recs * rec_bytes;
   const RawDma rr(a.rec, static_cast<unsigned>(a.n_clusters) * words * 4u);
   const RawDma rt(a.table, a.table_bytes);
   const RawDma rw(a.winners, BWD ? a.winners_bytes : 0);
@@ -318,12 +314,12 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
       const unsigned cluster = static_cast<unsigned>(lo + j + t * per_xcd) >> 1;
       const int word = 256 * wave + 4 * lane;
       const unsigned voff = word < words ? (cluster * static_cast<unsigned>(words) + word) * 4u : 0xFFFFFFF0u;
-      rr(lds + (t % 3) * rec_bytes + 1024 * wave, voff);
+      rr(lds + (t % n_recs) * rec_bytes + 1024 * wave, voff);
     }
   };
-  auto issue_gathers = [&](int t) {         // this wave's share of unit t's gathers; its record is in LDS
-    const int32_t* l_rec = reinterpret_cast<const int32_t*>(lds + (t % 3) * rec_bytes);
-    unsigned char* image = images + (t & 1) * image_bytes;
+  auto issue_gathers = [&](int t) {         // this wave's share of unit t's gathers; its record is in LDS.  Returns their count
+    const int32_t* l_rec = reinterpret_cast<const int32_t*>(lds + (t % n_recs) * rec_bytes);
+    unsigned char* image = images + (t % n_images) * image_bytes;
     const int n_srcs = l_rec[1];
     const int part = (lo + j + t * per_xcd) & 1;
     const int half = lane >> 5;
@@ -345,21 +341,29 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
         ++k8;
         return id;
       });
+      return k + k8;
     }
+    return k;
   };
 
-  fetch_record(0);
-  if (1 < n_my) fetch_record(1);
+  // Per iteration a wave issues, in this order: [record fetch of unit it + depth + 1 (waves 0 / 1)] [gathers of unit it + depth]
+  // [stores of unit it].  At the top of iteration `it` the gathers of unit `it` (issued `depth` iterations ago) and the record
+  // fetched in iteration it - 1 must have landed; vector-memory operations retire in order, so everything YOUNGER than that
+  // record fetch may stay in flight: the previous iteration's stores and, for depth >= 2, its gathers (for depth 1 those ARE
+  // the gathers of unit `it`).
+  for (int t = 0; t <= depth && t < n_my; ++t) fetch_record(t);
   barrier_all();
-  issue_gathers(0);
-  int stores = 0;                           // stores this wave issued after its last gathers
+  int pending_gathers = 0, stores = 0;
+  for (int t = 0; t < depth && t < n_my; ++t) pending_gathers = WHATIF != 1 ? issue_gathers(t) : 0;
+  if (depth == 1) pending_gathers = 0;
   for (int it = 0; it < n_my; ++it) {
-    wait_vm_all_but(stores);                // my gathers of unit `it` (and the record I fetched) have landed
-    barrier_lds();                          // ... and everyone else's; the other image and the oldest record slot are free
-    if (it + 1 < n_my && WHATIF != 1) issue_gathers(it + 1);
-    if (it + 2 < n_my) fetch_record(it + 2);
-    const int32_t* l_rec = reinterpret_cast<const int32_t*>(lds + (it % 3) * rec_bytes);
-    const unsigned char* image = images + (it & 1) * image_bytes;
+    wait_vm_all_but(pending_gathers + stores);
+    barrier_lds();                          // ... and everyone else's; the oldest image and the oldest record slot are free
+    if (it + depth + 1 < n_my) fetch_record(it + depth + 1);
+    pending_gathers = (it + depth < n_my && WHATIF != 1) ? issue_gathers(it + depth) : 0;
+    if (depth == 1) pending_gathers = 0;    // they are the gathers the next iteration waits for
+    const int32_t* l_rec = reinterpret_cast<const int32_t*>(lds + (it % n_recs) * rec_bytes);
+    const unsigned char* image = images + (it % n_images) * image_bytes;
     const int part = (lo + j + it * per_xcd) & 1;
     if constexpr (WHATIF == 2)
       stores = 0;
@@ -532,9 +536,14 @@ inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_
   }
   const int64_t units = 2LL * a.n_clusters;
   if (g_cluster_kernel != 2) {
-    // persistent streaming form: three record slots + two images per workgroup, as many workgroups per CU as fit (<= 2)
-    const int64_t wg_lds = 3LL * 1024 * ((a.layout.words + 255) / 256) + 2LL * (p.slot_bytes - p.image_off);
+    // persistent streaming form: depth + 2 record slots + depth + 1 images per workgroup; two workgroups per CU.  Depth 2 (gathers
+    // two units ahead) when that fits into half a CU's LDS, else depth 1
+    const int64_t rec_slot = 1024LL * ((a.layout.words + 255) / 256), image = p.slot_bytes - p.image_off;
+    int depth = g_cluster_ring > 0 ? std::min(g_cluster_ring, 4) : (4 * rec_slot + 3 * image <= kMaxLds / 2 ? 2 : 1);
+    while (depth > 1 && (depth + 2) * rec_slot + (depth + 1) * image > kMaxLds) --depth;
+    const int64_t wg_lds = (depth + 2) * rec_slot + (depth + 1) * image;
     if (wg_lds > kMaxLds || a.layout.words > 512) return GTS_ERR_SHAPE;
+    a.ring = depth;
     const int waves = g_cluster_consumers > 0 ? std::min(16, g_cluster_consumers) : (BWD ? 12 : 16);
     if (a.max_srcs > 64 * waves) return GTS_ERR_SHAPE;
     const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g_cluster_per_cu > 0 ? g_cluster_per_cu : 2, kMaxLds / wg_lds)));

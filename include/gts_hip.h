@@ -382,7 +382,7 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
 #define GTS_OPT_PANEL_ROWS 13        /* K11 direct-to-fragment panels: rows per panel, 0 = automatic among 240 / 192 / 144 */
 #define GTS_OPT_CLUSTER_KERNEL 9     /* clustered K1 / K2: 0 = persistent streaming workgroups (default), 1 = one workgroup per unit,
                                         2 = persistent workgroups with loader waves feeding a ring of slots to consumer waves */
-#define GTS_OPT_CLUSTER_RING 10      /* form 2: ring slots per workgroup (0 = as many as fit, at most 4) */
+#define GTS_OPT_CLUSTER_RING 10      /* form 0: units the gathers run ahead of the reduction (0 = automatic, 1 .. 4); form 2: ring slots per workgroup */
 #define GTS_OPT_CLUSTER_PER_CU 11    /* forms 0 / 2: persistent workgroups per CU (0 = automatic) */
 #define GTS_OPT_CLUSTER_CONSUMERS 12 /* form 0: waves per workgroup (default 8); form 2: consumer waves (0 = automatic) */
 int32_t gts_set_option(int32_t option, int32_t value);

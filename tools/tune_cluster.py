@@ -42,9 +42,9 @@ for b in [int(a) for a in sys.argv[1:]] or [4, 8, 32]:
           f"clusters={s_in.n_clusters}/{s_out.n_clusters} staged/row={s_in.staged_rows / n:.2f}/{s_out.staged_rows / n:.2f} "
           f"slot={s_in.lds_bytes(0)}/{s_out.lds_bytes(1)} B", flush=True)
     # (label, enabled, {option: value}): 9 = kernel form, 10 = ring slots, 11 = workgroups per CU, 12 = consumer waves
-    variants = [("plain", False, {}), ("unit-wg", True, {9: 1}), ("stream 8w x2", True, {}),
-                ("stream 8w x3", True, {11: 3}), ("stream 8w x4", True, {11: 4}), ("stream 6w x4", True, {11: 4, 12: 6}),
-                ("stream 4w x2", True, {12: 4}), ("stream 8w x1", True, {11: 1}), ("ring=3 cons=5", True, {9: 2, 10: 3, 12: 5})]
+    variants = [("plain", False, {}), ("unit-wg", True, {9: 1}), ("stream auto", True, {}),
+                ("stream depth 1", True, {10: 1}), ("stream depth 2", True, {10: 2}), ("stream depth 3", True, {10: 3}),
+                ("stream depth 2, 12 waves", True, {10: 2, 12: 12}), ("stream depth 2, 8 waves", True, {10: 2, 12: 8})]
     for label, enabled, options in variants:
         schedule.ENABLED = enabled
         for k, v in options.items():
