@@ -1623,7 +1623,7 @@ inline void wgrad_candidate(int variant, int64_t k, int* bm, int* bn, int64_t* s
   *bm = 128, *bn = k <= 64 ? 64 : 128, *slots = 512;   // 2 workgroups per CU
   if (k <= 64) return;
   if (variant == 2) *bn = 256;
-  if (variant == 4 || variant == 5 || variant == 7) *bm = 256, *bn = 256, *slots = 256;  // one workgroup per CU
+  if (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 9) *bm = 256, *bn = 256, *slots = 256;  // one workgroup per CU
 }
 
 inline WgradPlan wgrad_plan(int64_t m, int64_t n, int64_t k, int n_problems) {
@@ -1667,6 +1667,8 @@ int launch_wgrad(const GemmArgs& p, const WgradPlan& plan, hipStream_t st) {
   switch (plan.variant) {
     case 2: return launch_tiles<128, 256, 2, 4, false, false>(p, np, splits, st);
     case 4: return launch_tiles<256, 256, 4, 4, false, false, true>(p, np, splits, st);
+    case 8: return launch_tiles<256, 256, 2, 4, false, false, true>(p, np, splits, st);   // 8 waves of 128 x 64: 0.375 LDS reads per MFMA
+    case 9: return launch_tiles<256, 256, 4, 2, false, false, true>(p, np, splits, st);   // 8 waves of 64 x 128
     case 7: {
       GemmArgs q = p;
       q.tiles_n = (p.rb + 255) / 256;
