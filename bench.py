@@ -13,7 +13,7 @@ graphs per GPU (N_b = 60 000 nodes, E_b = 345 400 edges), in_feats 4, fp32, laye
 scaling: per-GPU work is fixed, global batch = graphs-per-gpu x N.
 
 Timing: after W warm-up steps the block of EXACTLY K steps (barrier + synchronize on both
-sides, MAX over ranks) is timed `--blocks` times (default 10); `value` is the MEDIAN block's
+sides, MAX over ranks) is timed `--blocks` times (default 30: ~3 s of GPU time at the headline shape); `value` is the MEDIAN block's
 rate and `blocks` carries min / median / max.  One further block of the same K steps runs
 with HIP events around every launch of the kernels the roofline objects describe.
 
@@ -89,7 +89,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--blocks", type=int, default=10,
+    ap.add_argument("--blocks", type=int, default=30,
                     help="the --steps block is timed this many times; value = the median block")
     ap.add_argument("--graphs-per-gpu", type=int, default=None,
                     help="graphs in one rank's batch (default 4; 8 for --config c4, 6 for --config real)")

@@ -638,7 +638,7 @@ struct PanelStage {   // one GEMM of the panel kernel: c[rows of the panel, rb] 
 // (any shape); without it the switches are compile-time facts and the output is whole 256-column blocks
 // (host-checked) — the epilogue of the layer-stack launches loses its ~50 uniform branches per 16 rows and
 // most of its code (the generic kernel is ~100 KB of instructions, more than the instruction cache).
-enum : int { kEpiBias = 1, kEpiRelu = 2, kEpiMaskBits = 4, kEpiBitsOut = 16, kEpiRuntime = 256, kEpiAbsent = -1 };
+enum : int { kEpiBias = 1, kEpiRelu = 2, kEpiMaskBits = 4, kEpiScores = 8, kEpiBitsOut = 16, kEpiRuntime = 256, kEpiAbsent = -1 };
 
 template <int WM, int WN, int DEPTH, int F = kEpiRuntime, int ROWS = kR240>
 __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int sched, int m0, int n0, int row_end) {
@@ -726,7 +726,7 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
   const bool col_ok = G ? col < s.rb : true;
   const bool has_bias = G ? s.bias != nullptr : (F & kEpiBias) != 0;
   const bool relu = G ? s.relu != 0 : (F & kEpiRelu) != 0;
-  const bool scores = G ? s.sc_l != nullptr : false;
+  const bool scores = G ? s.sc_l != nullptr : (F & kEpiScores) != 0;
   v4f bias = {0.f, 0.f, 0.f, 0.f};
   if (wide && has_bias && col_ok) bias = *reinterpret_cast<const v4f*>(s.bias + col);
   v4f sc_wl = {0.f, 0.f, 0.f, 0.f}, sc_wr = sc_wl;
@@ -882,8 +882,9 @@ int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
   if (p.c2 != nullptr) q.sched &= ~2;   // chained launches read their own output back through L1 / L2: ordinary stores only
   if constexpr (WM == 3 && WN == 4 && DEPTH == 1 && std::is_same<Probe, NoProbe>::value) {
     // the launches of the SAGE-pool layer stack at its 256-wide layers: compile-time epilogues
-    const bool whole = p.rb % kC240 == 0 && p.ldc % 4 == 0 && p.sc_l == nullptr && (p.mask == nullptr || p.bits_in != nullptr) &&
-                       (p.c2 == nullptr || (p.rb2 % kC240 == 0 && p.ldc2 % 4 == 0)) && !(q.sched & 2) && !(q.sched & 4);
+    const bool whole_cols = p.rb % kC240 == 0 && p.ldc % 4 == 0 && (p.mask == nullptr || p.bits_in != nullptr) &&
+                            (p.c2 == nullptr || (p.rb2 % kC240 == 0 && p.ldc2 % 4 == 0)) && !(q.sched & 2) && !(q.sched & 4);
+    const bool whole = whole_cols && p.sc_l == nullptr;
     const int f1 = (p.bias ? kEpiBias : 0) | (p.relu ? kEpiRelu : 0) | (p.mask ? kEpiMaskBits : 0) | (p.bits_out ? kEpiBitsOut : 0);
     const int f2 = p.c2 == nullptr ? kEpiAbsent : (p.bias2 ? kEpiBias : 0) | (p.relu2 ? kEpiRelu : 0);
     constexpr int kFwd = kEpiBias | kEpiRelu;
@@ -901,6 +902,10 @@ int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
     }
     if (whole && f1 == kFwd && f2 == kEpiAbsent) {                    // one biased ReLU layer on its own (fc_pool of the first wide layer)
       gemm_panel_direct_kernel<3, 4, 1, NoProbe, kFwd, kEpiAbsent, ROWS><<<grid, 768, 0, st>>>(q);
+      return launch_status();
+    }
+    if (whole_cols && p.sc_l != nullptr && f1 == 0 && f2 == kEpiAbsent) {   // GATConv's fc with the attention scores in its epilogue
+      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kEpiScores, kEpiAbsent, ROWS><<<grid, 768, 0, st>>>(q);
       return launch_status();
     }
     if (whole && f1 == 0 && f2 == kEpiAbsent) {                       // a plain product (g @ W_neigh of the top layer)
