@@ -100,6 +100,29 @@ def test_clustered_path_is_the_one_that_runs_at_the_c2_shape():
     assert torch.equal(ops.spmm_max_bwd(g, gout, arg), _plain(lambda: ops.spmm_max_bwd(g, gout, arg)))
 
 
+def test_generator_b_forced_through_the_schedule_is_bit_exact_too():
+    """Generator B (ring + uniform random pairs) shares almost no neighbours between rows, so the policy never schedules
+    it; forced through the clustered kernels anyway (every edge its own staged row) it must give the same bits."""
+    old = schedule.WORTHWHILE
+    schedule.WORTHWHILE = 10.0
+    try:
+        g = synth.random_graph(n=15000, n_pairs=30000, seed=1000)
+        s_in, s_out = g.cluster_schedule("in"), g.cluster_schedule("out")
+        assert s_in is not None and s_out is not None and s_in.staged_rows > 0.8 * s_in.n_edges
+        gd = g.to(DEV)
+        x = torch.relu(torch.randn(g.n, 256, device=DEV))
+        gout = torch.randn(g.n, 256, device=DEV)
+        out, arg = ops.spmm_max_fwd(gd, x, relu_input=True)
+        out_p, arg_p = _plain(lambda: ops.spmm_max_fwd(gd, x, relu_input=True))
+        assert torch.equal(out, out_p) and torch.equal(arg, arg_p)
+        assert torch.equal(ops.spmm_max_bwd(gd, gout, arg), _plain(lambda: ops.spmm_max_bwd(gd, gout, arg)))
+        tg = torch_ref.TGraph(graph_ref.RefGraph(g.src, g.dst, g.n))
+        out_ref, arg_ref = torch_ref.spmm_max_with_arg(tg, x.cpu())
+        assert torch.equal(out.cpu(), out_ref)
+    finally:
+        schedule.WORTHWHILE = old
+
+
 def test_other_widths_and_unworthy_graphs_take_the_plain_kernels():
     g = synth.random_graph(n=3000, n_pairs=6000, seed=1).to(DEV)
     assert g.dev_schedule("in") is None
