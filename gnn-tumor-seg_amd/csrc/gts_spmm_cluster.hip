@@ -356,24 +356,46 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
   int pending_gathers = 0, stores = 0;
   for (int t = 0; t < depth && t < n_my; ++t) pending_gathers = WHATIF != 1 ? issue_gathers(t) : 0;
   if (depth == 1) pending_gathers = 0;
+  // WHATIF == 9 (tools/diag only): shader-clock stamps of wave 0 around the phases of an iteration, summed per workgroup into
+  // `arg` (which then is a buffer of 8 x uint64 per workgroup, not the winners): wait for gathers | barrier | issue | reduce
+  unsigned long long phase[4] = {0, 0, 0, 0}, stamp = 0;
+  auto lap = [&](int which) {
+    if constexpr (WHATIF == 9) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      phase[which] += now - stamp;
+      stamp = now;
+    }
+  };
+  if constexpr (WHATIF == 9) stamp = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < n_my; ++it) {
     wait_vm_all_but(pending_gathers + stores);
+    lap(0);
     barrier_lds();                          // ... and everyone else's; the oldest image and the oldest record slot are free
+    lap(1);
     if (it + depth + 1 < n_my) fetch_record(it + depth + 1);
     pending_gathers = (it + depth < n_my && WHATIF != 1) ? issue_gathers(it + depth) : 0;
     if (depth == 1) pending_gathers = 0;    // they are the gathers the next iteration waits for
+    lap(2);
     const int32_t* l_rec = reinterpret_cast<const int32_t*>(lds + (it % n_recs) * rec_bytes);
     const unsigned char* image = images + (it % n_images) * image_bytes;
     const int part = (lo + j + it * per_xcd) & 1;
     if constexpr (WHATIF == 2)
       stores = 0;
-    else if constexpr (WHATIF >= 3 && !BWD)
+    else if constexpr (WHATIF >= 3 && WHATIF <= 4 && !BWD)
       stores = WHATIF == 3 ? (reduce_max_rows<ARGB, WHATIF>(a, l_rec, image, part, wave, n_waves), 0)
                            : reduce_max_rows<ARGB, WHATIF>(a, l_rec, image, part, wave, n_waves);
     else if constexpr (BWD)
       stores = reduce_winner_rows(a, l_rec, image, image + ((a.max_srcs + 1) & ~1) * kHalfBytes, part, wave, n_waves);
     else
       stores = reduce_max_rows<ARGB>(a, l_rec, image, part, wave, n_waves);
+    lap(3);
+  }
+  if constexpr (WHATIF == 9) {
+    if (threadIdx.x == 0) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.arg) + 8 * static_cast<size_t>(blockIdx.x);
+      for (int q = 0; q < 4; ++q) dbg[q] = phase[q];
+      dbg[4] = static_cast<unsigned long long>(n_my);
+    }
   }
 }
 

@@ -25,5 +25,6 @@ extern "C" int gts_whatif_cluster(const int32_t* rec, int64_t n_clusters, int32_
   if (whatif == 2) return launch_cluster<false, 1, 2>(a, max_rows, loc_words, st);
   if (whatif == 3) return launch_cluster<false, 1, 3>(a, max_rows, loc_words, st);
   if (whatif == 4) return launch_cluster<false, 1, 4>(a, max_rows, loc_words, st);
+  if (whatif == 9) return launch_cluster<false, 0, 9>(a, max_rows, loc_words, st);   // arg = stamp buffer, no winners written
   return launch_cluster<false, 1, 0>(a, max_rows, loc_words, st);
 }

@@ -59,3 +59,27 @@ for b in [int(a) for a in sys.argv[1:]] or [8]:
                                               None if bwd else args[i].data_ptr(), bwd, whatif, n, st)
                 assert code == 0, code
             print(f"B={b} {'K2' if bwd else 'K1'} {label:24s}: {timeit(run, n_sets):7.1f} us", flush=True)
+
+# ---- where an iteration of the persistent K1 kernel spends its time (wave 0 of every workgroup, shader clock)
+import numpy as np  # noqa: E402
+
+for b in (4, 8):
+    g = gts.batch([synth.lattice_graph() for _ in range(b)]).to("cuda")
+    n = g.n
+    x = torch.randn(n, 256, device="cuda").relu_()
+    out = torch.empty_like(x)
+    ds = g.dev_schedule("in")
+    h = ds.host
+    dbg = torch.zeros(8 * 4096, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        assert lib.gts_whatif_cluster(ds.packed.data_ptr(), h.n_clusters, h.limits[0], h.limits[1], h.loc_words, x.data_ptr(),
+                                      None, out.data_ptr(), dbg.data_ptr(), 0, 9, n, st) == 0
+    torch.cuda.synchronize()
+    d = dbg.cpu().numpy().reshape(-1, 8)
+    d = d[d[:, 4] > 0]
+    per_it = d[:, :4] / d[:, 4:5]
+    tot = per_it.sum(1).mean()
+    print(f"B={b}: {len(d)} workgroups, {d[:, 4].mean():.1f} units each; cycles per unit {tot:.0f} = wait for gathers "
+          f"{per_it[:, 0].mean():.0f} | barrier {per_it[:, 1].mean():.0f} | issue {per_it[:, 2].mean():.0f} | reduce + stores "
+          f"{per_it[:, 3].mean():.0f}", flush=True)
