@@ -68,6 +68,9 @@ inline int launch_status() {
   return e == hipSuccess ? GTS_OK : static_cast<int>(e);
 }
 
+// out[c] = sum over chunks of partial[chunk][c], fixed association (gts_gat_reduce.hip); cols % 4 == 0
+int sum_chunks(const float* partial, float* out, int cols, int chunks, hipStream_t st);
+
 // smallest power of two >= x, capped at 64 (lanes that cooperate on one row)
 inline int lanes_per_row(int64_t vec_cols) {
   int l = 1;

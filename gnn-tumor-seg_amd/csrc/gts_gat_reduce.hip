@@ -21,8 +21,8 @@ inline int n_chunks(int64_t n) {
 }
 
 __global__ __launch_bounds__(kBlock) void gat_act_bwd_kernel(
-    const float* __restrict__ gout, const float* __restrict__ out, int act,
-    float* __restrict__ g_pre, float* __restrict__ partial, int64_t n, int cols, int64_t rpc) {
+    const float* gout, const float* __restrict__ out, int act,
+    float* g_pre /* may be gout itself: every element is read, then written, by one thread */, float* __restrict__ partial, int64_t n, int cols, int64_t rpc) {
   const int64_t row0 = blockIdx.x * rpc, row1 = min(n, row0 + rpc);
   const int cols4 = cols >> 2;
   for (int q = threadIdx.x; q < cols4; q += kBlock) {
@@ -96,6 +96,11 @@ inline bool bad(int64_t n, int64_t cols) {
 }
 
 }  // namespace
+
+int sum_chunks(const float* partial, float* out, int cols, int chunks, hipStream_t st) {
+  sum_chunks_kernel<<<(cols / 4 + 15) / 16, kBlock, 0, st>>>(partial, out, cols, chunks);
+  return launch_status();
+}
 }  // namespace gts
 
 extern "C" int64_t gts_gat_reduce_workspace(int64_t n, int64_t cols) {

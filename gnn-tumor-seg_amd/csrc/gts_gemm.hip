@@ -75,6 +75,12 @@ struct GemmArgs {
   // bits_in: the same mask as `mask`, read by the kernels that can (the others read the floats of `mask`)
   unsigned long long* bits_out;
   const unsigned long long* bits_in;
+  // the activation backward of the layer BELOW riding in an input gradient's epilogue (panel kernels only; GATConv stacks):
+  // mask_kind 1 = ELU through its output: c *= mask > 0 ? 1 : mask + 1 (mask = that layer's output, read as floats);
+  // col_partial [row blocks][rb]: column sums of the rows each wave stored (the bias gradient of the layer below, summed
+  // over the row blocks in fixed order by sum_chunks)
+  int mask_kind;
+  float* col_partial;
 };
 
 // Phase probe of the kernel (start / operands staged / main loop done / tile stored).  The
@@ -632,13 +638,15 @@ struct PanelStage {   // one GEMM of the panel kernel: c[rows of the panel, rb] 
   float* sc_er;
   unsigned long long* bits_out;        // optional: sign bits of c (see GemmArgs)
   const unsigned long long* bits_in;   // optional: `mask` as bits
+  int mask_kind;                       // 0: ReLU mask, 1: ELU derivative through `mask` (see GemmArgs)
+  float* col_partial;                  // optional: column sums per wave row block
 };
 
 // What the epilogue of a stage does, as template bits: with kEpiRuntime every switch is read from the arguments
 // (any shape); without it the switches are compile-time facts and the output is whole 256-column blocks
 // (host-checked) — the epilogue of the layer-stack launches loses its ~50 uniform branches per 16 rows and
 // most of its code (the generic kernel is ~100 KB of instructions, more than the instruction cache).
-enum : int { kEpiBias = 1, kEpiRelu = 2, kEpiMaskBits = 4, kEpiScores = 8, kEpiBitsOut = 16, kEpiRuntime = 256, kEpiAbsent = -1 };
+enum : int { kEpiBias = 1, kEpiRelu = 2, kEpiMaskBits = 4, kEpiScores = 8, kEpiBitsOut = 16, kEpiEluSums = 32, kEpiRuntime = 256, kEpiAbsent = -1 };
 
 template <int WM, int WN, int DEPTH, int F = kEpiRuntime, int ROWS = kR240>
 __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int sched, int m0, int n0, int row_end) {
@@ -743,12 +751,15 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
   const bool bits_wanted = G ? bits_here && s.bits_out != nullptr : (F & kEpiBitsOut) != 0;
   const size_t bits_at = (static_cast<size_t>((n0 + wn * WTN) >> 6) * ((s.ra + 3) >> 2) + ((m0 + wm * WTM) >> 2)) * 4;
   unsigned long long* bit_words = reinterpret_cast<unsigned long long*>(lds + WM * WN * kStage) + wave * kBitWords;
+  const bool elu_mask = G ? s.mask_kind == 1 : (F & kEpiEluSums) != 0;
+  const bool col_sums = G ? s.col_partial != nullptr : (F & kEpiEluSums) != 0;
+  v4f csum = {0.f, 0.f, 0.f, 0.f};   // this lane's four columns over the rows it stores (rsub, rsub + 4, ...: fixed order)
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int row_base = m0 + wm * WTM + tm * 16;
     if (wide) {
       v4f mk[16 / kRowsPerIt];
-      const bool float_mask = G ? s.mask != nullptr && !bit_mask : false;
+      const bool float_mask = G ? s.mask != nullptr && !bit_mask : (F & kEpiEluSums) != 0;
       if (float_mask) {
 #pragma unroll
         for (int it = 0; it < 16 / kRowsPerIt; ++it) {
@@ -781,8 +792,10 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
           }
           if (float_mask) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) val[e] = mk[it][e] > 0.f ? val[e] : 0.f;
+            for (int e = 0; e < 4; ++e)
+              val[e] = mk[it][e] > 0.f ? val[e] : elu_mask ? val[e] * (mk[it][e] + 1.0f) : 0.f;
           }
+          if (col_sums) csum += val;
           v4f* dst = reinterpret_cast<v4f*>(s.c + static_cast<size_t>(row) * s.ldc + col);
           if (G && (sched & 2)) __builtin_nontemporal_store(val, dst);
           else *dst = val;
@@ -823,6 +836,15 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
       }
     }
   }
+  static_assert(kC4 == 16 || !(F & kEpiEluSums), "column sums: 64-column wave tiles");
+  if (col_sums && wide && kC4 == 16) {   // the four row residues of a column group sit 16 lanes apart: two fixed-order exchanges
+#pragma unroll
+    for (int e = 0; e < 4; ++e) csum[e] += __shfl_xor(csum[e], 16, kWave);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) csum[e] += __shfl_xor(csum[e], 32, kWave);
+    if (lane < kC4 && col_ok)
+      *reinterpret_cast<v4f*>(s.col_partial + static_cast<size_t>((m0 / ROWS) * WM + wm) * s.rb + col) = csum;
+  }
   if (bits_wanted) {
     __builtin_amdgcn_wave_barrier();
     const int valid = min(kBitWords, ((row_end - (m0 + wm * WTM) + 3) >> 2) * 4);   // words of rows that exist
@@ -849,7 +871,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
   s0.kseg[0] = p.kseg[0], s0.kseg[1] = p.kseg[1];
   s0.ra = p.ra, s0.rb = p.rb, s0.ldc = p.ldc, s0.relu = p.relu, s0.c = p.c, s0.bias = p.bias, s0.mask = p.mask;
   s0.sc_l = p.sc_l, s0.sc_r = p.sc_r, s0.sc_el = p.sc_el, s0.sc_er = p.sc_er;
-  s0.bits_out = p.bits_out, s0.bits_in = p.bits_in;
+  s0.bits_out = p.bits_out, s0.bits_in = p.bits_in, s0.mask_kind = p.mask_kind, s0.col_partial = p.col_partial;
   panel_stage<WM, WN, DEPTH, F1, ROWS>(s0, lds, p.sched, m0, n0, row_end);
   Probe::mark(2);
   // With c2 set a second GEMM follows in the same launch: the rows this workgroup has just stored are
@@ -884,7 +906,13 @@ int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
     // the launches of the SAGE-pool layer stack at its 256-wide layers: compile-time epilogues
     const bool whole_cols = p.rb % kC240 == 0 && p.ldc % 4 == 0 && (p.mask == nullptr || p.bits_in != nullptr) &&
                             (p.c2 == nullptr || (p.rb2 % kC240 == 0 && p.ldc2 % 4 == 0)) && !(q.sched & 2) && !(q.sched & 4);
-    const bool whole = whole_cols && p.sc_l == nullptr;
+    const bool whole = whole_cols && p.sc_l == nullptr && p.mask_kind == 0 && p.col_partial == nullptr;
+    if (p.rb % kC240 == 0 && p.ldc % 4 == 0 && p.mask_kind == 1 && p.mask != nullptr && p.col_partial != nullptr &&
+        p.bits_in == nullptr && p.bits_out == nullptr && p.sc_l == nullptr && p.c2 == nullptr && p.bias == nullptr &&
+        !p.relu && !(q.sched & 6)) {   // an input gradient through the ELU of the layer below, with that layer's bias gradient
+      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kEpiEluSums, kEpiAbsent, ROWS><<<grid, 768, 0, st>>>(q);
+      return launch_status();
+    }
     const int f1 = (p.bias ? kEpiBias : 0) | (p.relu ? kEpiRelu : 0) | (p.mask ? kEpiMaskBits : 0) | (p.bits_out ? kEpiBitsOut : 0);
     const int f2 = p.c2 == nullptr ? kEpiAbsent : (p.bias2 ? kEpiBias : 0) | (p.relu2 ? kEpiRelu : 0);
     constexpr int kFwd = kEpiBias | kEpiRelu;
@@ -1922,6 +1950,52 @@ extern "C" int32_t gts_linear_bwd_input_t_f32(const float* g0, const float* w0t,
   p.mask = relu_mask, p.bits_in = reinterpret_cast<const unsigned long long*>(relu_bits);
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
   return launch_plain<true, true>(p, static_cast<hipStream_t>(stream));
+}
+
+// The panel launch that can carry an activation backward + column sums in its epilogue: tall, whole 256-column blocks.
+static bool act_fold_in_epilogue(const gts::GemmArgs& p) {
+  return gts::pick_plain_variant<true, true>(p) == 10 && p.rb % gts::kC240 == 0;
+}
+
+extern "C" int64_t gts_linear_bwd_input_t_act_workspace(int64_t m, int64_t k) {
+  if (m <= 0 || k <= 0) return 0;
+  const int64_t row_blocks = (m + 143) / 144 * 3;   // the shortest panel: most row blocks
+  const int64_t pass = gts_gat_reduce_workspace(m, k) / 2;
+  const int64_t fold = row_blocks * k * static_cast<int64_t>(sizeof(float));
+  return fold > pass ? fold : pass;
+}
+
+extern "C" int32_t gts_linear_bwd_input_t_act_f32(const float* g0, const float* w0t, const float* g1, const float* w1t,
+                                                  const float* act_out, int32_t activation, float* gin, float* g_bias,
+                                                  float* workspace, int64_t workspace_bytes, int64_t m, int64_t k,
+                                                  int64_t n0, int64_t n1, void* stream) {
+  using namespace gts;
+  if (!g0 || !w0t || !gin || !act_out || ((g1 == nullptr) != (w1t == nullptr)) || (g_bias && !workspace)) return GTS_ERR_NULL;
+  if (activation != 1 && activation != 2) return GTS_ERR_ARGKIND;
+  if (m < 0 || k <= 0 || n0 <= 0 || n1 < 0 || m >= (1LL << 31) || k >= (1 << 20) || n0 >= (1 << 20) || n1 >= (1 << 20) ||
+      !aligned4(k) || !aligned4(n0) || !aligned4(n1) || (g1 && n1 == 0))
+    return GTS_ERR_SHAPE;
+  if (g_bias && workspace_bytes < gts_linear_bwd_input_t_act_workspace(m, k)) return GTS_ERR_SHAPE;
+  if (m == 0) return GTS_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  GemmArgs p{};
+  p.a[0] = g0, p.b[0] = w0t, p.lda[0] = p.ldb[0] = static_cast<int>(n0), p.kseg[0] = static_cast<int>(n0);
+  p.a[1] = g1 ? g1 : g0, p.b[1] = w1t ? w1t : w0t;
+  p.lda[1] = p.ldb[1] = static_cast<int>(n1), p.kseg[1] = g1 ? static_cast<int>(n1) : 0;
+  p.ra = static_cast<int>(m), p.rb = static_cast<int>(k), p.c = gin, p.ldc = static_cast<int>(k);
+  p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
+  if (activation == 1 && g_bias && act_fold_in_epilogue(p)) {
+    const int rows = panel_rows_for(p.ra, p.rb / kC240);
+    const int row_blocks = (p.ra + rows - 1) / rows * 3;
+    p.mask = act_out, p.mask_kind = 1, p.col_partial = workspace;
+    const int rc = launch_plain<true, true>(p, st);
+    if (rc != GTS_OK) return rc;
+    return sum_chunks(workspace, g_bias, p.rb, row_blocks, st);
+  }
+  // every other shape: the product, then the activation backward as the pass of its own (in place)
+  const int rc = launch_plain<true, true>(p, st);
+  if (rc != GTS_OK) return rc;
+  return gts_gat_act_bwd_f32(gin, act_out, activation, gin, g_bias, workspace, workspace_bytes, m, k, stream);
 }
 
 extern "C" int64_t gts_linear_bwd_weight_workspace(int64_t m, int64_t n, int64_t k,

@@ -301,6 +301,37 @@ def linear_bwd_input_t(g0, w0t, g1=None, w1t=None, relu_mask=None, relu_bits=Non
     return gin
 
 
+def linear_bwd_input_t_act(g0, w0t, act_out, activation, g1=None, w1t=None, want_bias_grad=True):
+    """(gin, g_bias): linear_bwd_input_t carried through the activation of the layer BELOW, whose output `act_out` [M,K] is
+    this layer's input (activation 1 = ELU, 2 = ReLU): gin = (g0 @ w0t^T (+ g1 @ w1t^T)) * act'(act_out), g_bias = gin.sum(0)
+    — at the tall 256-column-block shapes inside the GEMM's epilogue, otherwise as the pass of its own; the same gin
+    either way."""
+    _same(_mat(g0, "g0").shape[1], _mat(w0t, "w0t").shape[1], "inner dims of g0 @ w0t^T")
+    if (g1 is None) != (w1t is None):
+        raise _lib.GtsError("g1 and w1t go together")
+    if g1 is not None:
+        _same(_mat(g1, "g1").shape[1], _mat(w1t, "w1t").shape[1], "inner dims of g1 @ w1t^T")
+        _same(g1.shape[0], g0.shape[0], "rows of g0 / g1")
+        _same(w1t.shape[0], w0t.shape[0], "rows of w0t / w1t")
+    m, k = g0.shape[0], w0t.shape[0]
+    _same(tuple(_mat(act_out, "act_out").shape), (m, k), "act_out vs result")
+    n0, n1 = g0.shape[1], g1.shape[1] if g1 is not None else 0
+    if k % 4 or n0 % 4 or n1 % 4:
+        raise _lib.GtsError("linear_bwd_input_t_act needs widths that are multiples of 4")
+    g0, w0t, g1, w1t, act_out = _dense(g0, w0t, g1, w1t, act_out)
+    dev = _chk(g0, w0t, g1, w1t, act_out)
+    lib = _lib.load()
+    gin = torch.empty((m, k), dtype=torch.float32, device=dev)
+    g_bias = torch.empty(k, dtype=torch.float32, device=dev) if want_bias_grad else None
+    nbytes = lib.gts_linear_bwd_input_t_act_workspace(m, k) if want_bias_grad else 0
+    ws = _workspace(dev, nbytes) if want_bias_grad else None
+    _timed("igrad", 2.0 * m * k * (n0 + n1), lambda: check(
+        lib.gts_linear_bwd_input_t_act_f32(ptr(g0), ptr(w0t), ptr(g1), ptr(w1t), ptr(act_out), activation, ptr(gin),
+                                           ptr(g_bias), ptr(ws), nbytes, m, k, n0, n1, current_stream()),
+        "gts_linear_bwd_input_t_act_f32"))
+    return gin, g_bias
+
+
 MAX_WGRAD_PROBLEMS = 32   # kMaxProblems of csrc/gts_gemm.hip
 
 

@@ -563,13 +563,30 @@ FUSE_GAT_LAYER = os.environ.get("GTS_FUSE_GAT", "1") != "0"
 FUSE_GAT_SCORES = os.environ.get("GTS_FUSE_GAT_SCORES", "1") != "0"   # el / er in the fc GEMM's epilogue (A/B switch)
 
 
+FOLD_GAT_ACT_BWD = os.environ.get("GTS_FOLD_GAT_ACT", "1") != "0"   # A/B switch of ActLink
+
+
+class ActLink:
+    """Joins a GATConv layer to the ONE layer that consumes its activated output (GAT.forward, reference
+    model/networks.py:61-63: `h = self.layers[l](g, h).flatten(1)` feeds only the next layer).  In the backward pass the
+    consumer's input-gradient GEMM then multiplies by ELU'(h) — its input h IS the producer's output — in its epilogue and
+    sums the producer's bias gradient there (`dense.linear_bwd_input_t_act`), and the producer skips its own pass over
+    [N, H*D] (`ops.gat_act_bwd`: three tensors of 245 MB at the C3 shapes).  Same g_pre bit for bit; the bias gradient is
+    summed in a different fixed order.  The gradient autograd hands from consumer to producer is then d loss / d
+    (pre-activation): do not link a layer whose output anything else reads."""
+    __slots__ = ("folded", "g_bias")
+
+    def __init__(self):
+        self.folded, self.g_bias = False, None
+
+
 class _GATLayer(torch.autograd.Function):
     """rst = act( softmax-attention aggregate of ft + res_fc(h) + bias ),  ft = h W^T viewed [N,H,D],
     el/er = <ft, attn_l/r>  — DGL GATConv (reference model/networks.py:46-58) as one node."""
 
     @staticmethod
     def forward(ctx, g, h, w_fc, attn_l, attn_r, bias, w_res, identity_res, slope, act_code, heads, dim,
-                need_bwd):
+                need_bwd, below=None, above=None):
         h = h.contiguous()
         n = h.shape[0]
         al, ar = attn_l.reshape(heads, dim), attn_r.reshape(heads, dim)
@@ -589,6 +606,7 @@ class _GATLayer(torch.autograd.Function):
             ctx.g, ctx.slope, ctx.act, ctx.identity_res = g, slope, act_code, identity_res
             ctx.save_for_backward(h, ft, el, er, attn, out if act_code else None, w_fc, al, ar, w_res)
             ctx.attn_shape = attn_l.shape
+            ctx.below, ctx.above = below, above if act_code == 1 else None
         return out
 
     @staticmethod
@@ -596,9 +614,13 @@ class _GATLayer(torch.autograd.Function):
         h, ft, el, er, attn, out, w_fc, al, ar, w_res = ctx.saved_tensors
         n, heads, dim = ft.shape
         need = ctx.needs_input_grad
-        g_pre, g_bias = ops.gat_act_bwd(gout.reshape(n, heads * dim),
-                                        out.view(n, heads * dim) if out is not None else None, ctx.act,
-                                        want_bias_grad=need[5])
+        if ctx.above is not None and ctx.above.folded:   # the layer above has applied ELU' and summed the bias gradient
+            g_pre, g_bias = gout.reshape(n, heads * dim), ctx.above.g_bias if need[5] else None
+            ctx.above.folded, ctx.above.g_bias = False, None
+        else:
+            g_pre, g_bias = ops.gat_act_bwd(gout.reshape(n, heads * dim),
+                                            out.view(n, heads * dim) if out is not None else None, ctx.act,
+                                            want_bias_grad=need[5])
         gft, gel, ger = ops._gat_bwd(ctx.g, ft, el, er, attn, g_pre.view(n, heads, dim), ctx.slope, al, ar)
         g_al, g_ar = ops.gat_param_grad(ft, gel, ger)
         gft2 = gft.view(n, heads * dim)
@@ -606,23 +628,31 @@ class _GATLayer(torch.autograd.Function):
         # wide layers: the input gradient runs in the forward GEMM's form on transposed weights
         turn = TRANSPOSED_IGRAD and need[1] and w_fc.shape[1] >= 128 and w_fc.shape[0] % 4 == 0 \
             and w_fc.shape[1] % 4 == 0 and n >= 4096
+        fold = turn and ctx.below is not None and not ctx.identity_res and FOLD_GAT_ACT_BWD
         if w_res is not None:
             (g_wfc, _), (g_wres, _) = dense.linear_bwd_weight_multi([(gft2, h, False), (g_pre, h, False)])
-            if turn:
+            if fold:
+                wt = dense.transpose_batch([w_fc, w_res])
+                gh, ctx.below.g_bias = dense.linear_bwd_input_t_act(gft2, wt[0], h, 1, g_pre, wt[1])
+                ctx.below.folded = True
+            elif turn:
                 wt = dense.transpose_batch([w_fc, w_res])
                 gh = dense.linear_bwd_input_t(gft2, wt[0], g_pre, wt[1])
             else:
                 gh = dense.linear_bwd_input(gft2, w_fc, g_pre, w_res) if need[1] else None
         else:
             g_wfc, _ = dense.linear_bwd_weight(gft2, h)
-            if turn:
+            if fold:
+                gh, ctx.below.g_bias = dense.linear_bwd_input_t_act(gft2, dense.transpose_batch([w_fc])[0], h, 1)
+                ctx.below.folded = True
+            elif turn:
                 gh = dense.linear_bwd_input_t(gft2, dense.transpose_batch([w_fc])[0])
             else:
                 gh = dense.linear_bwd_input(gft2, w_fc) if need[1] else None
             if gh is not None and ctx.identity_res:
                 gh = gh + g_pre
         return (None, gh, g_wfc, g_al.view(ctx.attn_shape), g_ar.view(ctx.attn_shape), g_bias, g_wres,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 class GATConv(nn.Module):
@@ -664,7 +694,9 @@ class GATConv(nn.Module):
         if isinstance(self.res_fc, nn.Linear):
             nn.init.xavier_normal_(self.res_fc.weight, gain=gain)
 
-    def forward(self, graph, feat):
+    def forward(self, graph, feat, below=None, above=None):
+        """`below` / `above`: optional ActLink objects shared with the GATConv that produced `feat` / the one that alone
+        consumes this layer's output (set by model.networks.GAT.forward; see ActLink)."""
         if not self._allow_zero_in_degree and graph.min_in_degree == 0:
             raise GraphError(
                 "There are 0-in-degree nodes in the graph, output for those nodes will be invalid. "
@@ -681,9 +713,11 @@ class GATConv(nn.Module):
             identity_res = isinstance(self.res_fc, nn.Identity)
             need_bwd = torch.is_grad_enabled() and (
                 h.requires_grad or any(p.requires_grad for p in self.parameters()))
+            if self.feat_drop.p > 0 and self.training:   # a real dropout sits between the producer's output and this input
+                below = None
             return _GATLayer.apply(graph, h, self.fc.weight, self.attn_l, self.attn_r, self.bias, w_res,
                                    identity_res, self.negative_slope, act_code, self._num_heads,
-                                   self._out_feats, need_bwd)
+                                   self._out_feats, need_bwd, below, above)
         ft = dense.linear(h, self.fc.weight).view(n, self._num_heads, self._out_feats)
         el = (ft * self.attn_l).sum(dim=-1)
         er = (ft * self.attn_r).sum(dim=-1)

@@ -8,7 +8,7 @@ modules registered under `layers.{i}` so checkpoints interchange (SURVEY.md §8b
 import torch.nn as nn
 import torch.nn.functional as F
 
-from gts.nn import GATConv, SAGEConv, sage_pool_stack
+from gts.nn import ActLink, GATConv, SAGEConv, sage_pool_stack
 
 _SAGE_AGGREGATORS = {"GSpool": "pool", "GSgcn": "gcn", "GSmean": "mean"}
 
@@ -56,10 +56,13 @@ class GAT(nn.Module):
         self.layers = nn.ModuleList(convs)
 
     def forward(self, g, inputs):
+        # every hidden output feeds the next layer and nothing else: its ELU backward and bias gradient ride in the next
+        # layer's input-gradient GEMM (gts.nn.ActLink; same values as layer-by-layer)
+        links = [ActLink() for _ in self.layers[:-1]]
         h = inputs
-        for conv in self.layers[:-1]:
-            h = conv(g, h).flatten(1)
-        return self.layers[-1](g, h).mean(1)
+        for i, conv in enumerate(self.layers[:-1]):
+            h = conv(g, h, below=links[i - 1] if i else None, above=links[i]).flatten(1)
+        return self.layers[-1](g, h, below=links[-1]).mean(1)
 
 
 class CnnRefinementNet(nn.Module):

@@ -274,6 +274,19 @@ int32_t gts_linear_bwd_input_f32(const float* g0, const float* w0, const float* 
 int32_t gts_linear_bwd_input_t_f32(const float* g0, const float* w0t, const float* g1, const float* w1t,
                                    const float* relu_mask, const uint64_t* relu_bits, float* gin, int64_t m,
                                    int64_t k, int64_t n0, int64_t n1, void* stream);
+/* the same input gradient carried through the activation of the layer BELOW (a GATConv stack: the next layer's input IS the
+ * ELU output of this one, model/networks.py:46-58,61-63), with that layer's bias gradient:
+ *   gin[m, k] = (g0 w0 (+ g1 w1)) * act'(act_out),  act' through the activation's OUTPUT act_out [m, k]: activation 1 = ELU
+ *   (1 where act_out > 0, act_out + 1 elsewhere), 2 = ReLU;  g_bias[k] = sum_m gin[m, k] (optional).
+ * Tall operands with k % 256 == 0 and ELU: both ride in the GEMM's epilogue (no pass over gin, column sums per 80-row block
+ * in `workspace` and added in fixed order); otherwise gts_linear_bwd_input_t_f32 followed by gts_gat_act_bwd_f32 in place.
+ * gin is bitwise the same either way; g_bias is summed in a different (each time fixed) order.
+ * workspace >= gts_linear_bwd_input_t_act_workspace(m, k) bytes when g_bias is asked for. */
+int64_t gts_linear_bwd_input_t_act_workspace(int64_t m, int64_t k);
+int32_t gts_linear_bwd_input_t_act_f32(const float* g0, const float* w0t, const float* g1, const float* w1t,
+                                       const float* act_out, int32_t activation, float* gin, float* g_bias,
+                                       float* workspace, int64_t workspace_bytes, int64_t m, int64_t k,
+                                       int64_t n0, int64_t n1, void* stream);
 /* GATConv's projection with its attention scores (model/networks.py:46,52,56 -> dgl GATConv: feat_src = fc(h).view(N, H, D);
  * el = (feat_src * attn_l).sum(-1); er likewise):  ft [m, heads*dim] = h [m, k] w_fc^T,  el/er [m, heads] = <ft[n,h,:], attn_l/r[h,:]>.
  * Tall operands with dim % 64 == 0: the dot products ride in the GEMM epilogue (partials per 64 columns in `workspace`,

@@ -370,3 +370,25 @@ def test_transposed_and_chained_entry_points_take_non_contiguous_operands():
     mask = torch.randn(k, m, device="cuda").t()          # non-contiguous ReLU source
     gin, gin2 = dense.linear_bwd_input_chain_t(g0, wt_strided, None, None, mask, torch.randn(8, k, device="cuda"))
     assert torch.equal(gin, dense.linear_bwd_input_t(g0.contiguous(), wt_view.contiguous(), relu_mask=mask.contiguous()))
+
+
+@pytest.mark.parametrize("m,k,n0,n1", [(60000, 1024, 1024, 0), (60000, 1024, 4, 0), (35000, 256, 256, 256), (59999, 512, 64, 64),
+                                        (4800, 512, 64, 0), (1000, 64, 32, 0), (5000, 260, 8, 0)])
+@pytest.mark.parametrize("activation", [1, 2])
+def test_input_gradient_through_the_activation_of_the_layer_below(m, k, n0, n1, activation):
+    """gts_linear_bwd_input_t_act_f32: (g0 w0 + g1 w1) * act'(act_out) and its column sums — in the epilogue of the panel
+    launch at the tall 256-column-block shapes (ELU), otherwise GEMM + gat_act_bwd in place.  gin must equal the two
+    separate calls bit for bit on either route; the bias gradient is a different fixed-order sum (fp64 yardstick)."""
+    from gts import ops
+    g0, w0t = _rand(m, n0, seed=1).to(DEV), _rand(k, n0, seed=2).to(DEV)
+    g1, w1t = (_rand(m, n1, seed=3).to(DEV), _rand(k, n1, seed=4).to(DEV)) if n1 else (None, None)
+    act_out = torch.nn.functional.elu(_rand(m, k, seed=5)).to(DEV) if activation == 1 else _rand(m, k, seed=5).relu().to(DEV)
+    plain = dense.linear_bwd_input_t(g0, w0t, g1, w1t)
+    want, want_bias = ops.gat_act_bwd(plain, act_out, activation, want_bias_grad=True)
+    got, got_bias = dense.linear_bwd_input_t_act(g0, w0t, act_out, activation, g1, w1t)
+    assert torch.equal(got, want)
+    sums64, bound = got.double().sum(0), got.double().abs().sum(0)
+    for bias in (got_bias, want_bias):
+        assert torch.all((bias.double() - sums64).abs() <= 2e-6 * bound + 1e-30)
+    only, none = dense.linear_bwd_input_t_act(g0, w0t, act_out, activation, g1, w1t, want_bias_grad=False)
+    assert none is None and torch.equal(only, want)

@@ -611,3 +611,29 @@ def test_sage_sum_layers_with_widths_that_are_not_multiples_of_four(aggr, fin, f
     _close(xd.grad, xr.grad, 1e-4, 1e-5)
     for (_, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
         _close(p.grad, q.grad, 1e-4, 2e-5 * max(1.0, float(q.grad.abs().max())))
+
+
+@pytest.mark.parametrize("n,hp", [(6000, HP(4, 4, [64] * 3, [4, 4, 4], [False, True, False])),
+                                  (60000, HP(4, 4, [64] * 2, [4, 4], [False, False]))])
+def test_gat_act_backward_in_the_next_layers_gemm_equals_the_pass_of_its_own(n, hp, monkeypatch):
+    """ActLink (GAT.forward): ELU' of a hidden layer and its bias gradient inside the next layer's input-gradient GEMM
+    (60 000 rows: the panel kernel's epilogue; 6 000 rows: GEMM + in-place pass) vs the layer-by-layer backward: every
+    gradient but the hidden biases bit for bit, those as a different fixed-order sum of the same numbers."""
+    src, dst = random_coo(n, 5 * n, seed=3, min_in_degree=1)
+    g = gts.Graph(src, dst, n).to(DEV)
+    _, mine = _net_pair("GAT", hp, seed=2)
+    x = torch.from_numpy(synth.node_features(n, hp.in_feats, 5)).to(DEV)
+    y = torch.from_numpy(synth.node_labels(n, 5)).to(DEV)
+    grads = {}
+    for fold in (True, False):
+        monkeypatch.setattr(gnn, "FOLD_GAT_ACT_BWD", fold)
+        mine.zero_grad(set_to_none=True)
+        F.cross_entropy(mine(g, x), y).backward()
+        grads[fold] = {k: p.grad.clone() for k, p in mine.named_parameters()}
+    for name, want in grads[False].items():
+        got = grads[True][name]
+        if name.endswith("bias") and not name.startswith(f"layers.{len(hp.layer_sizes)}."):
+            scale = float(want.abs().max()) + 1e-30
+            assert float((got - want).abs().max()) <= 1e-4 * scale + 1e-9, name
+        else:
+            assert torch.equal(got, want), name
