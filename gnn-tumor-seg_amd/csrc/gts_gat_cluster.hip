@@ -1,0 +1,498 @@
+// GATConv's weighted neighbour aggregation (K5 - K7) and the source pass of its backward (K8) at D = 256 over a
+// CLUSTER ROW SCHEDULE: the LDS-staged neighbour tiles of gts_spmm_cluster.hip, four times wider.
+//
+// The plain kernels (gts_gat.hip) give one wave to every (node, head) row and fetch one 1 KiB slice per (edge,
+// head) through the CU's L1 out of a table of N x H KiB (245 MB at the C3 shapes) behind the row's index chain:
+// 0.30 - 0.36 of the HBM peak.  Here a unit of work is one 512-byte column half of one head of one cluster of
+// the graph's schedule (gts/schedule.py, the records of gts_cluster_schedule): 2 H units per cluster, the unit's
+// distinct neighbour slices staged once in LDS by LDS-DMA, persistent workgroups (two per CU), gathers one unit
+// ahead of the reduction — the streaming form of spmm_cluster_stream_kernel, see there for the pipeline.
+//
+// What differs from the max-pool reducers is the arithmetic of a row: a weighted sum, weights = the row's edge
+// softmax.  They come from a pass of their own (`gat_attn_kernel`: the same expressions in the same association
+// as gat_fwd_kernel, so attn [E, H] is bit-identical) and are laid out per (cluster, head) in the order of the
+// record's 8-edge chunks (`gat_arrange_kernel`) so that a unit's weights arrive by ONE more LDS-DMA with its
+// record; the reduction then adds `w_k * slice_k` in CSR slot order exactly as the plain kernels do.  Bias + ELU
+// (forward) and `gel * attn_l + ger * attn_r` (backward) ride in the row's epilogue out of a third small LDS-DMA.
+// Rows keep their place: the schedule only decides which workgroup computes which row.
+#include <algorithm>
+
+#include "gts_cluster.h"
+
+namespace gts {
+namespace {
+
+__device__ __forceinline__ float leaky_relu(float x, float slope) { return x > 0.0f ? x : x * slope; }
+
+template <int G>
+__device__ __forceinline__ float lanes_sum(float x) {   // xor butterfly inside the aligned group of G lanes (as group_sum of gts_gat.hip)
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, kWave);
+  return x;
+}
+template <int G>
+__device__ __forceinline__ float lanes_max(float x) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) x = fmaxf(x, __shfl_xor(x, m, kWave));
+  return x;
+}
+
+// ---- the edge softmax of every (node, head) row: attn [E, H] --------------------------------------------------
+// G lanes per row, G >= the largest in-degree (host-checked).  gat_fwd_kernel reduces over the 64 lanes of a wave
+// with the row's edges in lanes 0 .. deg-1 and neutral elements elsewhere; the steps of its butterfly that reach
+// beyond an aligned group of G lanes add exact zeros (the maximum: -inf), so the G-lane butterfly gives the same
+// bits with 64 / G rows per wave.
+template <int G>
+__global__ __launch_bounds__(kBlock) void gat_attn_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                          const float* __restrict__ el, const float* __restrict__ er, float slope,
+                                                          float* __restrict__ attn, int n_rows, int heads) {
+  const int gl = threadIdx.x % G;
+  const long long r = (static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x) / G;
+  const bool live = r < n_rows;
+  const int v = live ? static_cast<int>(r / heads) : 0, h = live ? static_cast<int>(r - static_cast<long long>(v) * heads) : 0;
+  const int beg = live ? indptr[v] : 0, deg = live ? indptr[v + 1] - beg : 0;
+  const bool mine = gl < deg;
+  const int idx = mine ? indices[beg + gl] : 0;
+  const float el_u = mine ? el[static_cast<size_t>(idx) * heads + h] : 0.0f;
+  const float er_v = live ? er[r] : 0.0f;
+  const float score = mine ? leaky_relu(el_u + er_v, slope) : -INFINITY;
+  const float m = lanes_max<G>(score);
+  const float den = lanes_sum<G>(mine ? expf(score - m) : 0.0f);
+  const float w = mine ? expf(score - m) / den : 0.0f;
+  if (mine) attn[static_cast<size_t>(beg + gl) * heads + h] = w;
+}
+
+// ---- weights (and per-row scalars) in the order of the schedule's records -------------------------------------
+// side [n_clusters][H][side_floats]: chunk weights [chunk_slots][8] (the record's 8-edge chunks; pads 0), then for the
+// backward pass per row of the cluster (gel, ger).  One thread per (cluster, row slot, head).
+//   forward : weight of the row's k-th in-edge  = attn[(indptr[v] + k) H + h]
+//   backward: weight of the row's k-th out-edge = attn[t_pos[t_indptr[u] + k] H + h];  gel[u, h] = sum_k ge[t_pos[..] H + h]
+//             in edge order (as gat_bwd_src_kernel adds them), also written to gel [N, H]
+template <bool BWD>
+__global__ __launch_bounds__(kBlock) void gat_arrange_kernel(const int32_t* __restrict__ rec, RecLayout layout, int n_clusters,
+                                                             int max_rows, int heads, const int32_t* __restrict__ row_ptr,
+                                                             const int32_t* __restrict__ t_pos, const float* __restrict__ attn,
+                                                             const float* __restrict__ ge, const float* __restrict__ ger,
+                                                             float* __restrict__ gel, float* __restrict__ side, int side_floats,
+                                                             int chunk_slots) {
+  const long long tid = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x;
+  const int per_cluster = max_rows * heads;
+  const long long c = tid / per_cluster;
+  if (c >= n_clusters) return;
+  const int rem = static_cast<int>(tid - c * per_cluster), j = rem / heads, h = rem - j * heads;
+  const int32_t* r = rec + static_cast<size_t>(c) * layout.words;
+  if (j >= r[0]) return;
+  const int row = r[layout.rows + j];
+  const uint32_t info = static_cast<uint32_t>(r[layout.eoff + j]);
+  const int c0 = info & 0xFFFF, deg = info >> 16;
+  const int beg = row_ptr[row];
+  float* block = side + (static_cast<size_t>(c) * heads + h) * side_floats;
+  float* dst = block + c0 * 8;
+  float gel_r = 0.0f;
+  const int padded = (deg + 7) & ~7;
+  for (int k = 0; k < padded; ++k) {
+    float w = 0.0f;
+    if (k < deg) {
+      const size_t pos = static_cast<size_t>(BWD ? t_pos[beg + k] : beg + k) * heads + h;
+      w = attn[pos];
+      if constexpr (BWD) gel_r += ge[pos];
+    }
+    dst[k] = w;
+  }
+  if constexpr (BWD) {
+    const size_t at = static_cast<size_t>(row) * heads + h;
+    gel[at] = gel_r;
+    float* scal = block + chunk_slots * 8 + j * 2;
+    scal[0] = gel_r;
+    scal[1] = ger != nullptr ? ger[at] : 0.0f;
+  }
+}
+
+// The two passes above in one, for graphs whose rows fit ONE 8-edge chunk (every graph the default rules send here): eight
+// lanes per (cluster, head, row slot) = the row's edges, walked in the ORDER OF THE RECORDS, so the weights land in their
+// blocks as whole 32-byte pieces next to each other (a record's rows own consecutive chunks).  Forward: the softmax itself
+// (lanes_max<8> / lanes_sum<8>: gat_fwd_kernel's bits, see gat_attn_kernel), attn [E, H] written on the way.  Backward: the
+// weights through t_pos, and gel[u, h] = the row's ge added in edge order across the eight lanes.
+template <bool BWD>
+__global__ __launch_bounds__(kBlock) void gat_weights_one_chunk_kernel(const int32_t* __restrict__ rec, RecLayout layout, int n_clusters,
+                                                                       int max_rows, int heads, const int32_t* __restrict__ row_ptr,
+                                                                       const int32_t* __restrict__ indices_or_pos,
+                                                                       const float* __restrict__ el, const float* __restrict__ er,
+                                                                       float slope, float* __restrict__ attn_out,
+                                                                       const float* __restrict__ attn_in, const float* __restrict__ ge,
+                                                                       const float* __restrict__ ger, float* __restrict__ gel,
+                                                                       float* __restrict__ side, int side_floats, int chunk_slots) {
+  // eight lanes per (cluster, row slot); every lane walks the heads (their values sit next to each other in el / er / attn / ge:
+  // one dependent chain of index loads per row instead of one per (row, head))
+  const unsigned idx = blockIdx.x * static_cast<unsigned>(kBlock) + threadIdx.x;   // < 2^31 (host-checked)
+  const int k = static_cast<int>(idx & 7);
+  const unsigned grp = idx >> 3;
+  const unsigned c = grp / static_cast<unsigned>(max_rows);
+  const int j = static_cast<int>(grp - c * max_rows);
+  const int32_t* r = rec + static_cast<size_t>(c < static_cast<unsigned>(n_clusters) ? c : 0u) * layout.words;
+  const bool live = c < static_cast<unsigned>(n_clusters) && j < r[0];
+  const int row = live ? r[layout.rows + j] : 0;
+  const uint32_t info = live ? static_cast<uint32_t>(r[layout.eoff + j]) : 0u;
+  const int c0 = info & 0xFFFF, deg = info >> 16;          // deg <= 8 (host-checked)
+  const int beg = live ? row_ptr[row] : 0;
+  const bool mine = k < deg;
+  const size_t at = static_cast<size_t>(row) * heads;
+  const size_t edge = mine ? static_cast<size_t>(BWD ? indices_or_pos[beg + k] : beg + k) * heads : 0;   // this lane's row of attn / ge
+  const size_t src = (!BWD && mine) ? static_cast<size_t>(indices_or_pos[beg + k]) * heads : 0;           // ... and of el
+  float* block = side + static_cast<size_t>(c) * heads * side_floats;
+  const int base = (threadIdx.x & (kWave - 1)) & ~7;
+#pragma unroll 4
+  for (int h = 0; h < heads; ++h) {
+    float w = 0.0f;
+    if constexpr (!BWD) {
+      const float el_u = mine ? el[src + h] : 0.0f;
+      const float er_v = live ? er[at + h] : 0.0f;
+      const float score = mine ? leaky_relu(el_u + er_v, slope) : -INFINITY;
+      const float m = lanes_max<8>(score);
+      const float den = lanes_sum<8>(mine ? expf(score - m) : 0.0f);
+      w = mine ? expf(score - m) / den : 0.0f;
+      if (mine) attn_out[edge + h] = w;
+    } else {
+      w = mine ? attn_in[edge + h] : 0.0f;
+      const float g = mine ? ge[edge + h] : 0.0f;
+      float gel_r = 0.0f;                                   // edge order; the lanes past the row's end add +0.0
+#pragma unroll
+      for (int q = 0; q < 8; ++q) gel_r += __shfl(g, base + q, kWave);
+      if (live && k == 0) {
+        gel[at + h] = gel_r;
+        float* scal = block + static_cast<size_t>(h) * side_floats + chunk_slots * 8 + j * 2;
+        scal[0] = gel_r;
+        scal[1] = ger != nullptr ? ger[at + h] : 0.0f;
+      }
+    }
+    if (live && deg > 0) block[static_cast<size_t>(h) * side_floats + c0 * 8 + k] = w;
+  }
+}
+
+// ---- the persistent streaming kernel ----------------------------------------------------------------------------
+struct GatClusterArgs {
+  const int32_t* rec;      // [n_clusters][layout.words]
+  RecLayout layout;
+  int n_clusters, max_srcs;
+  const float* table;      // forward: ft [N, H, 256];  backward: g_pre [N, H, 256]
+  const float* side;       // gat_arrange_kernel's blocks
+  const float* vec;        // forward: bias [H, 256] or null;  backward: attn_l | attn_r [2][H, 256] or null
+  float* out;              // forward: out [N, H, 256];  backward: gft
+  unsigned table_bytes, side_bytes, vec_bytes;
+  int heads, act;
+  int side_floats, chunk_slots, side_pieces;
+  int rec_bytes, side_slot_bytes, image_bytes;   // LDS: 3 record slots | 3 side slots | 3 vector slots of 1 KiB | 2 images
+};
+
+// the rows of one unit out of LDS: half a wave per row, 16 B per lane; acc += w_k * slice_k in slot order, one
+// straight-line body per exact edge count of an 8-edge chunk.  Returns the number of store instructions issued.
+template <bool BWD>
+__device__ __forceinline__ int reduce_wsum_rows(const GatClusterArgs& a, const int32_t* l_rec, const unsigned char* image,
+                                                const float* l_side, const float* l_vec, int sub, int first, int step) {
+  const int lane = threadIdx.x & (kWave - 1), half = lane >> 5, hl = lane & 31;
+  const int n_rows = l_rec[0];
+  const uint32_t* info = reinterpret_cast<const uint32_t*>(l_rec + a.layout.eoff);
+  const uint2* loc = reinterpret_cast<const uint2*>(l_rec + a.layout.loc);
+  const unsigned char* mine = image + hl * 16;
+  int trips = 0;
+  for (int j0 = 2 * first; j0 < n_rows; j0 += 2 * step, ++trips) {   // j0 is wave-uniform: the even row of the pair
+    const int j = j0 + half;
+    const bool have = j < n_rows;
+    const uint32_t ri = have ? info[j] : 0u;
+    const int c0 = ri & 0xFFFF, deg = ri >> 16;
+    const int deg_w = max(__builtin_amdgcn_readlane(deg, 0), __builtin_amdgcn_readlane(deg, 32));
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; 8 * c < deg_w; ++c) {
+      const int at = 8 * c < deg ? c0 + c : c0;                 // the shorter row of the pair re-reads its first chunk, masked below
+      const uint2 w = loc[at];
+      const float4 wa = *reinterpret_cast<const float4*>(l_side + at * 8), wb = *reinterpret_cast<const float4*>(l_side + at * 8 + 4);
+      const float wts[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+      for_count(min(8, deg_w - 8 * c), [&](auto cnt_c) {
+        constexpr int CNT = decltype(cnt_c)::value;
+        float4 val[CNT];
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) val[q] = *reinterpret_cast<const float4*>(mine + chunk_byte(w, q) * kHalfBytes);
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+          const bool live = 8 * c + q < deg;
+          const float v4[4] = {val[q].x, val[q].y, val[q].z, val[q].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] = live ? acc[t] + wts[q] * v4[t] : acc[t];
+        }
+      });
+    }
+    Vec<4> o{{acc[0], acc[1], acc[2], acc[3]}};
+    if constexpr (BWD) {
+      if (a.vec != nullptr) {   // el = <ft, attn_l>, er = <ft, attn_r>: their gradient w.r.t. ft
+        const float2 sc = have ? *reinterpret_cast<const float2*>(l_side + a.chunk_slots * 8 + j * 2) : float2{0.f, 0.f};
+        const float4 al = *reinterpret_cast<const float4*>(l_vec + hl * 4), ar = *reinterpret_cast<const float4*>(l_vec + 128 + hl * 4);
+        const float al4[4] = {al.x, al.y, al.z, al.w}, ar4[4] = {ar.x, ar.y, ar.z, ar.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o.v[t] += sc.x * al4[t] + sc.y * ar4[t];
+      }
+    } else {
+      if (a.vec != nullptr) {
+        const float4 bs = *reinterpret_cast<const float4*>(l_vec + hl * 4);
+        o.v[0] += bs.x, o.v[1] += bs.y, o.v[2] += bs.z, o.v[3] += bs.w;
+      }
+      if (a.act == 1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o.v[t] = o.v[t] > 0.0f ? o.v[t] : expm1f(o.v[t]);
+      }
+    }
+    if (have) o.store(a.out + (static_cast<size_t>(l_rec[a.layout.rows + j]) * a.heads * kF + sub * (kF / 2) + hl * 4));
+  }
+  return trips;
+}
+
+// gridDim.x is a multiple of 8: the workgroups with blockIdx % 8 == x (one XCD under round-robin placement; speed only)
+// share the x-th eighth of the CLUSTERS and walk its units sub-unit by sub-unit (all clusters of the span for head 0 /
+// left half, then head 0 / right half, ...), round-robin: the units in flight on an XCD at one time are the same
+// column half of neighbouring clusters, whose halo slices meet in its L2.
+// MINW = 8: up to 16 waves per workgroup at <= 64 registers; 6: up to 12 waves at <= 80 (two workgroups per CU either way)
+template <bool BWD, int MINW>
+__global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const GatClusterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int n_waves = blockDim.x / kWave;
+  const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int subs = 2 * a.heads;
+  const int clo = static_cast<int>(static_cast<long long>(a.n_clusters) * xcd / 8);
+  const int span = static_cast<int>(static_cast<long long>(a.n_clusters) * (xcd + 1) / 8) - clo;
+  const long long n_local = static_cast<long long>(span) * subs;
+  const int n_my = jw < n_local ? static_cast<int>((n_local - jw + per_xcd - 1) / per_xcd) : 0;
+  if (n_my == 0) return;
+  const int words = a.layout.words;
+  const int rec_pieces = a.rec_bytes / 1024;
+  unsigned char* side_slots = lds + 3 * a.rec_bytes;
+  unsigned char* vec_slots = side_slots + 3 * a.side_slot_bytes;
+  unsigned char* images = vec_slots + 3 * 1024;
+  const RawDma rr(a.rec, static_cast<unsigned>(a.n_clusters) * words * 4u);
+  const RawDma rt(a.table, a.table_bytes);
+  const RawDma rs(a.side, a.side_bytes);
+  const RawDma rv(a.vec, a.vec != nullptr ? a.vec_bytes : 0);
+  auto unit = [&](int t, int* sub) {        // t-th unit of this workgroup: its cluster, and which (head, half) of it
+    const unsigned i = static_cast<unsigned>(jw) + static_cast<unsigned>(t) * per_xcd;   // < 2^31 (host-checked)
+    const unsigned s = i / static_cast<unsigned>(span);
+    *sub = static_cast<int>(s);
+    return clo + static_cast<int>(i - s * span);
+  };
+  auto fetch_record = [&](int t) {          // record, weights and epilogue vectors of unit t -> their slots, one LDS-DMA per piece and wave
+    int sub;
+    const unsigned cluster = static_cast<unsigned>(unit(t, &sub));
+    const int slot = t % 3;
+    if (wave < rec_pieces) {
+      const int word = 256 * wave + 4 * lane;
+      rr(lds + slot * a.rec_bytes + 1024 * wave, word < words ? (cluster * static_cast<unsigned>(words) + word) * 4u : 0xFFFFFFF0u);
+    } else if (wave < rec_pieces + a.side_pieces) {
+      const int p = wave - rec_pieces, word = 256 * p + 4 * lane;
+      const unsigned base = (cluster * static_cast<unsigned>(a.heads) + static_cast<unsigned>(sub >> 1)) * static_cast<unsigned>(a.side_floats);
+      rs(side_slots + slot * a.side_slot_bytes + 1024 * p, word < a.side_floats ? (base + word) * 4u : 0xFFFFFFF0u);
+    } else if (wave == rec_pieces + a.side_pieces && a.vec != nullptr) {
+      // 128 floats of this (head, half) from each vector: lanes 0-31 the first (bias / attn_l), lanes 32-63 the second (attn_r)
+      const unsigned first = static_cast<unsigned>(sub) * 128u + (lane & 31) * 4u;
+      const unsigned off = (lane < 32 ? first : BWD ? static_cast<unsigned>(a.heads) * kF + first : 0x3FFFFFFCu) * 4u;
+      rv(vec_slots + slot * 1024, off);
+    }
+  };
+  auto issue_gathers = [&](int t) {         // this wave's share of unit t's gathers; its record is in LDS
+    int sub;
+    unit(t, &sub);
+    const int32_t* l_rec = reinterpret_cast<const int32_t*>(lds + (t % 3) * a.rec_bytes);
+    unsigned char* image = images + (t & 1) * a.image_bytes;
+    const int n_srcs = l_rec[1];
+    // lane l keeps the id of row 2 (wave + n_waves (l / 2)) + l % 2: every row pair this wave fetches, one LDS read
+    const int last = pad4(a.max_srcs) - 1;
+    const int32_t ids = l_rec[a.layout.srcs + min(2 * (wave + n_waves * (lane >> 1)) + (lane & 1), last)];
+    const unsigned row_bytes = static_cast<unsigned>(a.heads) * (kF * 4u);
+    const unsigned col = static_cast<unsigned>(sub) * kHalfBytes + (lane & 31) * 16u;
+    int k = 0;
+    for (int i = 2 * wave; i < n_srcs; i += 2 * n_waves, ++k) {
+      const int s0 = __builtin_amdgcn_readlane(ids, 2 * k), s1 = __builtin_amdgcn_readlane(ids, 2 * k + 1);
+      rt(image + i * kHalfBytes, static_cast<unsigned>(lane < 32 ? s0 : s1) * row_bytes + col);
+    }
+  };
+
+  // Per iteration a wave issues, in this order: [record / weights / vectors of unit it + 2] [gathers of unit it + 1] [stores
+  // of unit it].  At the top of iteration `it` everything but the stores of the iteration before must have landed
+  // (vector-memory operations retire in order).
+  fetch_record(0);
+  if (n_my > 1) fetch_record(1);
+  barrier_all();
+  issue_gathers(0);
+  int stores = 0;
+  for (int it = 0; it < n_my; ++it) {
+    wait_vm_all_but(stores);
+    barrier_lds();                          // ... and everyone else's; the other image and the oldest slots are free
+    if (it + 2 < n_my) fetch_record(it + 2);
+    if (it + 1 < n_my) issue_gathers(it + 1);
+    int sub;
+    unit(it, &sub);
+    const int slot = it % 3;
+    stores = reduce_wsum_rows<BWD>(a, reinterpret_cast<const int32_t*>(lds + slot * a.rec_bytes), images + (it & 1) * a.image_bytes,
+                                   reinterpret_cast<const float*>(side_slots + slot * a.side_slot_bytes),
+                                   reinterpret_cast<const float*>(vec_slots + slot * 1024), sub, wave, n_waves);
+  }
+}
+
+struct GatPlan {
+  int chunk_slots, side_floats, side_pieces, rec_bytes, side_slot_bytes, image_bytes, waves;
+  int64_t wg_lds;
+};
+inline GatPlan gat_plan(int max_rows, int max_srcs, int loc_words, bool tagged, bool bwd) {
+  GatPlan p;
+  p.chunk_slots = loc_words / 2;
+  p.side_floats = p.chunk_slots * 8 + (bwd ? max_rows * 2 : 0);
+  p.side_pieces = (p.side_floats + 255) / 256;
+  p.rec_bytes = 1024 * ((rec_layout(max_rows, max_srcs, loc_words, tagged).words + 255) / 256);
+  p.side_slot_bytes = 1024 * p.side_pieces;
+  p.image_bytes = ((max_srcs + 1) & ~1) * kHalfBytes;
+  p.waves = g_gat_cluster_waves > 0 ? std::max(4, std::min(16, g_gat_cluster_waves)) : 12;
+  p.wg_lds = 3LL * p.rec_bytes + 3LL * p.side_slot_bytes + 3 * 1024 + 2LL * p.image_bytes;
+  return p;
+}
+
+inline bool bad_gat_cluster(int64_t n_clusters, int32_t max_rows, int32_t max_srcs, int32_t loc_words, bool tagged, bool bwd,
+                            int64_t n, int64_t heads, int64_t dim) {
+  if (n_clusters < 0 || n_clusters >= (1 << 28) || max_rows < 1 || max_srcs < 1 || max_srcs > 256 || loc_words < 2 ||
+      loc_words % 4 != 0 || n < 0 || heads < 1 || heads > 64 || dim != kF)
+    return true;
+  if (n * heads * kF * 4 >= (1LL << 32) || n_clusters * heads * 2 + 4096 >= (1LL << 31)) return true;   // 32-bit byte offsets into the table; unit ids
+  if (n_clusters * rec_layout(max_rows, max_srcs, loc_words, tagged).words * 4 >= (1LL << 32)) return true;
+  if (n_clusters * max_rows * 8 + 4096 >= (1LL << 31)) return true;                               // thread ids of the weight pass
+  const GatPlan p = gat_plan(max_rows, max_srcs, loc_words, tagged, bwd);
+  if (n_clusters * heads * p.side_floats * 4 >= (1LL << 32)) return true;     // ... and into the weight blocks
+  if (rec_layout(max_rows, max_srcs, loc_words, tagged).words > 512 || p.wg_lds > kMaxLds) return true;
+  if (p.rec_bytes / 1024 + p.side_pieces + 1 > p.waves || max_srcs > 64 * p.waves || max_rows > 2 * 64) return true;
+  return false;
+}
+
+template <bool BWD>
+int launch_gat_cluster(GatClusterArgs a, const GatPlan& p, hipStream_t st) {
+  a.side_floats = p.side_floats, a.chunk_slots = p.chunk_slots, a.side_pieces = p.side_pieces;
+  a.rec_bytes = p.rec_bytes, a.side_slot_bytes = p.side_slot_bytes, a.image_bytes = p.image_bytes;
+  const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({g_cluster_per_cu > 0 ? g_cluster_per_cu : 2, kMaxLds / p.wg_lds,
+                                                                               static_cast<int64_t>(32 / p.waves)})));
+  const int64_t units = 2LL * a.heads * a.n_clusters;
+  int64_t grid = static_cast<int64_t>(device_cus()) * per_cu;
+  grid = std::max<int64_t>(8, std::min(grid, (units + 7) / 8 * 8)) / 8 * 8;
+  static const bool once = (allow_big_lds(gat_cluster_stream_kernel<BWD, 6>), allow_big_lds(gat_cluster_stream_kernel<BWD, 8>), true);
+  (void)once;
+  if (p.waves > 12) gat_cluster_stream_kernel<BWD, 8><<<dim3(static_cast<unsigned>(grid)), p.waves * kWave, p.wg_lds, st>>>(a);
+  else gat_cluster_stream_kernel<BWD, 6><<<dim3(static_cast<unsigned>(grid)), p.waves * kWave, p.wg_lds, st>>>(a);
+  return launch_status();
+}
+
+template <typename Launch>
+int for_group_size(int64_t max_degree, Launch&& launch) {
+  if (max_degree <= 8) return launch(IC<8>{});
+  if (max_degree <= 16) return launch(IC<16>{});
+  if (max_degree <= 32) return launch(IC<32>{});
+  return launch(IC<64>{});
+}
+
+}  // namespace
+}  // namespace gts
+
+extern "C" int64_t gts_gat_cluster_workspace(int64_t n_clusters, int32_t max_rows, int32_t loc_words, int64_t heads,
+                                             int32_t backward) {
+  if (n_clusters < 0 || max_rows < 1 || loc_words < 2 || heads < 1) return 0;
+  const int64_t side_floats = (loc_words / 2) * 8 + (backward ? max_rows * 2 : 0);
+  return n_clusters * heads * side_floats * static_cast<int64_t>(sizeof(float));
+}
+
+extern "C" int32_t gts_gat_attn_f32(const int32_t* indptr, const int32_t* indices, const float* el, const float* er,
+                                    float negative_slope, float* attn, int64_t n, int64_t heads, int64_t max_degree,
+                                    void* stream) {
+  using namespace gts;
+  if (!indptr || !el || !er || !attn) return GTS_ERR_NULL;
+  if (n < 0 || heads < 1 || n * heads >= (1LL << 31) || max_degree < 0 || max_degree > kWave) return GTS_ERR_SHAPE;
+  if (n == 0 || max_degree == 0) return GTS_OK;
+  if (!indices) return GTS_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nr = static_cast<int>(n * heads), nh = static_cast<int>(heads);
+  return for_group_size(max_degree, [&](auto g_c) {
+    constexpr int G = decltype(g_c)::value;
+    const int64_t threads = static_cast<int64_t>(nr) * G;
+    gat_attn_kernel<G><<<static_cast<unsigned>((threads + kBlock - 1) / kBlock), kBlock, 0, st>>>(indptr, indices, el, er, negative_slope,
+                                                                                                 attn, nr, nh);
+    return launch_status();
+  });
+}
+
+extern "C" int32_t gts_gat_fwd_cluster_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rec, int64_t n_clusters,
+                                           int32_t max_rows, int32_t max_srcs, int32_t loc_words, int32_t tagged, const float* ft,
+                                           const float* el, const float* er, float negative_slope, const float* bias,
+                                           int32_t activation, float* out, float* attn, float* workspace, int64_t workspace_bytes,
+                                           int64_t n, int64_t heads, int64_t dim, int64_t max_degree, void* stream) {
+  using namespace gts;
+  if (!indptr || !rec || !ft || !el || !er || !out || !attn || !workspace) return GTS_ERR_NULL;
+  if (bad_gat_cluster(n_clusters, max_rows, max_srcs, loc_words, tagged != 0, false, n, heads, dim)) return GTS_ERR_SHAPE;
+  if (activation != 0 && activation != 1) return GTS_ERR_ARGKIND;
+  if (workspace_bytes < gts_gat_cluster_workspace(n_clusters, max_rows, loc_words, heads, 0)) return GTS_ERR_SHAPE;
+  if (n == 0 || n_clusters == 0) return GTS_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const GatPlan p = gat_plan(max_rows, max_srcs, loc_words, tagged != 0, false);
+  const RecLayout lay = rec_layout(max_rows, max_srcs, loc_words, tagged != 0);
+  const int nh = static_cast<int>(heads);
+  const int64_t threads = n_clusters * max_rows * heads;
+  int rc = GTS_OK;
+  if (max_degree <= 8) {
+    if (!indices && max_degree > 0) return GTS_ERR_NULL;
+    gat_weights_one_chunk_kernel<false><<<static_cast<unsigned>((8 * (threads / heads) + kBlock - 1) / kBlock), kBlock, 0, st>>>(
+        rec, lay, static_cast<int>(n_clusters), max_rows, nh, indptr, indices, el, er, negative_slope, attn, nullptr, nullptr, nullptr,
+        nullptr, workspace, p.side_floats, p.chunk_slots);
+  } else {
+    rc = gts_gat_attn_f32(indptr, indices, el, er, negative_slope, attn, n, heads, max_degree, stream);
+    if (rc != GTS_OK) return rc;
+    gat_arrange_kernel<false><<<static_cast<unsigned>((threads + kBlock - 1) / kBlock), kBlock, 0, st>>>(
+        rec, lay, static_cast<int>(n_clusters), max_rows, nh, indptr, nullptr, attn, nullptr, nullptr, nullptr, workspace, p.side_floats,
+        p.chunk_slots);
+  }
+  rc = launch_status();
+  if (rc != GTS_OK) return rc;
+  GatClusterArgs a{};
+  a.rec = rec, a.layout = lay, a.n_clusters = static_cast<int>(n_clusters), a.max_srcs = max_srcs;
+  a.table = ft, a.side = workspace, a.vec = bias, a.out = out;
+  a.table_bytes = static_cast<unsigned>(n * heads * kF * 4);
+  a.side_bytes = static_cast<unsigned>(n_clusters * heads * p.side_floats * 4);
+  a.vec_bytes = static_cast<unsigned>(heads * kF * 4);
+  a.heads = nh, a.act = activation;
+  return launch_gat_cluster<false>(a, p, st);
+}
+
+extern "C" int32_t gts_gat_bwd_src_cluster_f32(const int32_t* t_indptr, const int32_t* t_pos, const int32_t* rec, int64_t n_clusters,
+                                               int32_t max_rows, int32_t max_srcs, int32_t loc_words, int32_t tagged,
+                                               const float* attn, const float* ge, const float* gout, const float* attn_lr,
+                                               const float* ger, float* gft, float* gel, float* workspace, int64_t workspace_bytes,
+                                               int64_t n, int64_t heads, int64_t dim, int64_t max_degree, void* stream) {
+  using namespace gts;
+  if (!t_indptr || !rec || !attn || !ge || !gout || !gft || !gel || !workspace) return GTS_ERR_NULL;
+  if ((attn_lr == nullptr) != (ger == nullptr)) return GTS_ERR_NULL;
+  if (bad_gat_cluster(n_clusters, max_rows, max_srcs, loc_words, tagged != 0, true, n, heads, dim)) return GTS_ERR_SHAPE;
+  if (workspace_bytes < gts_gat_cluster_workspace(n_clusters, max_rows, loc_words, heads, 1)) return GTS_ERR_SHAPE;
+  if (n == 0 || n_clusters == 0) return GTS_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const GatPlan p = gat_plan(max_rows, max_srcs, loc_words, tagged != 0, true);
+  const RecLayout lay = rec_layout(max_rows, max_srcs, loc_words, tagged != 0);
+  const int nh = static_cast<int>(heads);
+  const int64_t threads = n_clusters * max_rows * heads;
+  if (max_degree >= 0 && max_degree <= 8)
+    gat_weights_one_chunk_kernel<true><<<static_cast<unsigned>((8 * (threads / heads) + kBlock - 1) / kBlock), kBlock, 0, st>>>(
+        rec, lay, static_cast<int>(n_clusters), max_rows, nh, t_indptr, t_pos, nullptr, nullptr, 0.0f, nullptr, attn, ge, ger, gel,
+        workspace, p.side_floats, p.chunk_slots);
+  else
+    gat_arrange_kernel<true><<<static_cast<unsigned>((threads + kBlock - 1) / kBlock), kBlock, 0, st>>>(
+        rec, lay, static_cast<int>(n_clusters), max_rows, nh, t_indptr, t_pos, attn, ge, ger, gel, workspace, p.side_floats, p.chunk_slots);
+  const int rc = launch_status();
+  if (rc != GTS_OK) return rc;
+  GatClusterArgs a{};
+  a.rec = rec, a.layout = lay, a.n_clusters = static_cast<int>(n_clusters), a.max_srcs = max_srcs;
+  a.table = gout, a.side = workspace, a.vec = attn_lr, a.out = gft;
+  a.table_bytes = static_cast<unsigned>(n * heads * kF * 4);
+  a.side_bytes = static_cast<unsigned>(n_clusters * heads * p.side_floats * 4);
+  a.vec_bytes = static_cast<unsigned>(2 * heads * kF * 4);
+  a.heads = nh, a.act = 0;
+  return launch_gat_cluster<true>(a, p, st);
+}

@@ -10,7 +10,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgts_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "gts_hip.h")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -34,6 +34,12 @@ SIGNATURES = {
     "gts_gat_scores_f32": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     "gts_gat_reduce_workspace": [_i64, _i64],
     "gts_gat_act_bwd_f32": [_p, _p, _i32, _p, _p, _p, _i64, _i64, _i64, _p],
+    "gts_gat_cluster_workspace": [_i64, _i32, _i32, _i64, _i32],
+    "gts_gat_attn_f32": [_p, _p, _p, _p, _f32, _p, _i64, _i64, _i64, _p],
+    "gts_gat_fwd_cluster_f32": [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _f32, _p, _i32, _p, _p, _p, _i64,
+                                _i64, _i64, _i64, _i64, _p],
+    "gts_gat_bwd_src_cluster_f32": [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i64,
+                                    _i64, _i64, _i64, _i64, _p],
     "gts_gat_param_grad_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "gts_gat_bwd_edge_f32": [_p, _p, _p, _p, _p, _p, _p, _f32, _p, _p, _i64, _i64, _i64, _p],
     "gts_gat_bwd_src_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
@@ -73,7 +79,7 @@ _RESTYPE = {"gts_error_string": ctypes.c_char_p, "gts_linear_bwd_weight_workspac
             "gts_weighted_ce_workspace": _i64, "gts_gat_reduce_workspace": _i64,
             "gts_label_confusion_workspace": _i64, "gts_gat_fc_scores_workspace": _i64,
             "gts_relu_bits_bytes": _i64, "gts_cluster_record_words": _i64, "gts_sage_pool_stack_fwd_arena": _i64, "gts_sage_pool_stack_bwd_scratch": _i64, "gts_cluster_lds_bytes": _i64,
-            "gts_linear_bwd_input_t_act_workspace": _i64}
+            "gts_linear_bwd_input_t_act_workspace": _i64, "gts_gat_cluster_workspace": _i64}
 
 _lib = None
 

@@ -165,6 +165,7 @@ class Graph:
         deg = np.diff(self.indptr)
         self.max_in_degree = int(deg.max()) if deg.size else 0
         self.min_in_degree = int(deg.min()) if deg.size else 0
+        self._max_out_degree = None
 
     def _coo(self):
         if self._src is None:
@@ -261,12 +262,19 @@ class Graph:
         return d
 
     @property
+    def max_out_degree(self):
+        if self._max_out_degree is None:
+            deg = np.diff(self.t_indptr)
+            self._max_out_degree = int(deg.max()) if deg.size else 0
+        return self._max_out_degree
+
+    @property
     def arg_bytes(self):
         return 1 if self.max_in_degree <= 254 else 4
 
     def cluster_schedule(self, which):
-        """Cluster row schedule of the in-CSR ('in': K1, rows = destinations) or of the out-CSR ('out': K2, rows =
-        sources, tagged with t_slot); None when clustering does not save enough row fetches on this graph (or a
+        """Cluster row schedule of the in-CSR ('in': K1, rows = destinations; 'gat_in': GATConv forward) or of the out-CSR
+        ('out': K2, rows = sources, tagged with t_slot; 'gat_out': GATConv backward); None when clustering does not save enough row fetches on this graph (or a
         row's degree is beyond a cluster).  Built once per host graph; a batch concatenates its members'."""
         from . import schedule as _schedule
 
@@ -279,15 +287,15 @@ class Graph:
                     sched = _schedule.ClusterSchedule.concat(parts, node_off)
             else:
                 lim = _schedule.limits(which)
-                if which == "in":
+                if which.endswith("in"):
                     sched = _schedule.ClusterSchedule.build(self.indptr, self.indices, self.t_indptr, self.t_indices,
                                                             None, lim)
-                else:
+                else:       # 'out' carries K2's tags (t_slot); 'gat_out' has no use for them
                     sched = _schedule.ClusterSchedule.build(self.t_indptr, self.t_indices, self.indptr, self.indices,
-                                                            self.t_slot, lim)
+                                                            self.t_slot if which == "out" else None, lim)
                 if sched is not None:
-                    degrees = np.diff(self.indptr if which == "in" else self.t_indptr)
-                    if not sched.worthwhile(int(degrees.max()) if degrees.size else 0):
+                    degrees = np.diff(self.indptr if which.endswith("in") else self.t_indptr)
+                    if not sched.worthwhile(int(degrees.max()) if degrees.size else 0, which):
                         sched = None
             self._sched[which] = sched
         return self._sched[which]

@@ -202,11 +202,46 @@ def _gat_fwd(g, ft, el, er, slope, bias=None, residual=None, activation=0):
     out = torch.empty_like(ft)
     attn = torch.empty((g.number_of_edges(), h), dtype=torch.float32, device=ft.device)
     lib = _lib.load()
-    launch = lambda: lib.gts_gat_fwd_f32(      # noqa: E731
-        ptr(d.indptr), ptr(d.indices), ptr(ft), ptr(el), ptr(er), float(slope), ptr(bias), ptr(residual),
-        activation, ptr(out), ptr(attn), n, h, dim, current_stream())
+    ds = _gat_cluster_schedule(g, "gat_in", n, h, dim) if residual is None else None
+    if ds is not None:      # LDS-staged neighbour slices over the graph's cluster row schedule: same result, bit for bit
+        hs = ds.host
+        nbytes = lib.gts_gat_cluster_workspace(hs.n_clusters, hs.limits[0], hs.loc_words, h, 0)
+        ws = _gat_ws(ft.device, nbytes)
+        launch = lambda: lib.gts_gat_fwd_cluster_f32(      # noqa: E731
+            ptr(d.indptr), ptr(d.indices), ptr(ds.packed), hs.n_clusters, hs.limits[0], hs.limits[1], hs.loc_words,
+            1 if hs.tagged else 0, ptr(ft), ptr(el), ptr(er), float(slope), ptr(bias), activation, ptr(out), ptr(attn),
+            ptr(ws), nbytes, n, h, dim, g.max_in_degree, current_stream())
+    else:
+        launch = lambda: lib.gts_gat_fwd_f32(      # noqa: E731
+            ptr(d.indptr), ptr(d.indices), ptr(ft), ptr(el), ptr(er), float(slope), ptr(bias), ptr(residual),
+            activation, ptr(out), ptr(attn), n, h, dim, current_stream())
     check(_timed("gat_fwd", launch) if h * dim >= 256 else launch(), "gts_gat_fwd_f32")
     return out, attn
+
+
+_gat_workspaces = {}
+
+
+def _gat_ws(device, nbytes):
+    """Scratch of the clustered GAT kernels (their weight blocks), grown on demand and reused: one per (device, stream)."""
+    key = (device, current_stream())
+    buf = _gat_workspaces.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _gat_workspaces[key] = buf
+    return buf
+
+
+def _gat_cluster_schedule(g, which, n, heads, dim):
+    """Device schedule for the clustered GATConv kernels, or None when they do not apply (D != 256, tables of 4 GiB and
+    more, small graphs, rows of more than one 8-edge chunk, no worthwhile schedule, GTS_CLUSTER_GAT=0)."""
+    from . import schedule
+
+    if not schedule.ENABLED_GAT or dim != 256 or n < schedule.MIN_ROWS_GAT or n * heads * 1024 >= 2 ** 32 or heads > 64:
+        return None
+    if which == "gat_in" and g.max_in_degree > 64:
+        return None
+    return g.dev_schedule(which)
 
 
 def _gat_bwd(g, ft, el, er, attn, gout, slope, attn_l=None, attn_r=None):
@@ -230,10 +265,21 @@ def _gat_bwd(g, ft, el, er, attn, gout, slope, attn_l=None, attn_r=None):
     check(_timed("gat_bwd_edge", edge) if wide else edge(), "gts_gat_bwd_edge_f32")
     gft = torch.empty_like(ft)
     gel = torch.empty_like(el)
-    src = lambda: lib.gts_gat_bwd_src_f32(ptr(d.t_indptr), ptr(d.t_indices), ptr(d.t_pos), ptr(attn), ptr(ge),     # noqa: E731
-                                          ptr(gout), ptr(attn_l), ptr(attn_r),
-                                          ptr(ger) if attn_l is not None else None, ptr(gft), ptr(gel), n, h, dim,
-                                          current_stream())
+    ds = _gat_cluster_schedule(g, "gat_out", n, h, dim)
+    if ds is not None:
+        hs = ds.host
+        nbytes = lib.gts_gat_cluster_workspace(hs.n_clusters, hs.limits[0], hs.loc_words, h, 1)
+        ws = _gat_ws(ft.device, nbytes)
+        attn_lr = torch.stack([attn_l.reshape(-1), attn_r.reshape(-1)]) if attn_l is not None else None
+        src = lambda: lib.gts_gat_bwd_src_cluster_f32(      # noqa: E731
+            ptr(d.t_indptr), ptr(d.t_pos), ptr(ds.packed), hs.n_clusters, hs.limits[0], hs.limits[1], hs.loc_words,
+            1 if hs.tagged else 0, ptr(attn), ptr(ge), ptr(gout), ptr(attn_lr), ptr(ger) if attn_l is not None else None,
+            ptr(gft), ptr(gel), ptr(ws), nbytes, n, h, dim, g.max_out_degree, current_stream())
+    else:
+        src = lambda: lib.gts_gat_bwd_src_f32(ptr(d.t_indptr), ptr(d.t_indices), ptr(d.t_pos), ptr(attn), ptr(ge),     # noqa: E731
+                                              ptr(gout), ptr(attn_l), ptr(attn_r),
+                                              ptr(ger) if attn_l is not None else None, ptr(gft), ptr(gel), n, h, dim,
+                                              current_stream())
     check(_timed("gat_bwd_src", src) if wide else src(), "gts_gat_bwd_src_f32")
     return gft, gel, ger
 

@@ -28,7 +28,9 @@ from . import _lib
 
 # (max rows, max distinct neighbour rows, max padded edges: rows take whole chunks of 8) per cluster.  One LDS ring slot (gts_cluster_lds_bytes) is
 # then about 39 KiB: four slots per persistent workgroup, one workgroup per CU.
-_DEFAULT_LIMITS = {"in": (32, 76, 512), "out": (32, 60, 512)}
+# 'gat_in' / 'gat_out': the GATConv aggregation over the in- / out-CSR (csrc/gts_gat_cluster.hip): its workgroups also hold three
+# weight blocks and three epilogue-vector slots, so the neighbour list is shorter (two workgroups of 78 KB per CU).
+_DEFAULT_LIMITS = {"in": (32, 76, 512), "out": (32, 60, 512), "gat_in": (32, 64, 256), "gat_out": (32, 64, 256)}
 # A schedule is used when it stages at most this share of the rows the plain kernel would fetch (one per edge).
 WORTHWHILE = float(os.environ.get("GTS_CLUSTER_WORTHWHILE", "0.6"))
 ENABLED = os.environ.get("GTS_CLUSTER_SPMM", "1") != "0"
@@ -46,14 +48,18 @@ MIN_ROWS_FORWARD = int(os.environ.get("GTS_CLUSTER_MIN_ROWS_FWD", "100000"))
 #       edges: 101 vs 90).
 MAX_MEAN_DEGREE_FORWARD = float(os.environ.get("GTS_CLUSTER_MAX_MEAN_DEGREE_FWD", "11"))
 MAX_DEGREE_BACKWARD = int(os.environ.get("GTS_CLUSTER_MAX_DEGREE_BWD", "8"))
+# GATConv over a schedule: rows of one 8-edge chunk, as K2 (the weighted sum costs per edge what K2's masked sum does)
+ENABLED_GAT = os.environ.get("GTS_CLUSTER_GAT", "1") != "0"
+MAX_DEGREE_GAT = int(os.environ.get("GTS_CLUSTER_MAX_DEGREE_GAT", "8"))
+MIN_ROWS_GAT = int(os.environ.get("GTS_CLUSTER_MIN_ROWS_GAT", "20000"))
 
 
 def limits(which):
     """Cluster limits for 'in' (K1) / 'out' (K2); GTS_CLUSTER_LIMITS="r,s,e;r,s,e" overrides (tuning runs)."""
-    env = os.environ.get("GTS_CLUSTER_LIMITS")
+    env = os.environ.get("GTS_GAT_CLUSTER_LIMITS" if which.startswith("gat_") else "GTS_CLUSTER_LIMITS")
     if env:
         both = [tuple(int(v) for v in part.split(",")) for part in env.split(";")]
-        return both[0 if which == "in" else 1]
+        return both[0 if which.endswith("in") else 1]
     return _DEFAULT_LIMITS[which]
 
 
@@ -97,11 +103,13 @@ class ClusterSchedule:
     def layout(self):
         return _Layout(self.limits[0], self.limits[1], self.loc_words, self.tagged)
 
-    def worthwhile(self, max_degree=None):
+    def worthwhile(self, max_degree=None, which=None):
         """Does the clustered kernel beat the plain one on this graph?  It must stage clearly fewer neighbour rows than
         the plain kernel fetches (one per edge), and the graph must be sparse enough for its reduction (see above)."""
         if self.n_edges == 0 or self.staged_rows > WORTHWHILE * self.n_edges:
             return False
+        if which is not None and which.startswith("gat_"):
+            return max_degree is None or max_degree <= MAX_DEGREE_GAT
         if self.tagged:      # K2
             return max_degree is None or max_degree <= MAX_DEGREE_BACKWARD
         return self.n_edges <= MAX_MEAN_DEGREE_FORWARD * self.n_rows

@@ -164,6 +164,32 @@ int32_t gts_gat_param_grad_f32(const float* ft, const float* gel, const float* g
                                float* g_attn_r, float* workspace, int64_t workspace_bytes, int64_t n,
                                int64_t heads, int64_t dim, void* stream);
 
+/* ---- K5-K8 at D = 256 over a cluster row schedule (LDS-staged neighbour tiles; csrc/gts_gat_cluster.hip) -----------------
+ * The same GATConv aggregation (model/networks.py:46,52,56 -> dgl GATConv: edge_softmax, u_mul_e + sum) and the source pass
+ * of its backward, computed per cluster of a schedule made by gts_cluster_schedule (records `rec`, limits max_rows / max_srcs,
+ * loc_words, tagged = the records carry the tag section): a unit of work is one 512-byte column half of one head of one
+ * cluster, its distinct neighbour slices staged once in LDS.  Same values as gts_gat_fwd_f32 / gts_gat_bwd_src_f32 bit for
+ * bit (edges in CSR slot order inside every row, the softmax in the plain kernel's association); no residual term here.
+ *   gts_gat_attn_f32: attn [E, H] alone (max_degree: the largest in-degree, <= 64).
+ *   forward: in-CSR (indptr, indices) + a schedule of the in-CSR;  bias [H*256] optional.
+ *   backward: out-CSR (t_indptr, t_pos) + a schedule of the out-CSR;  attn_lr = attn_l | attn_r stacked [2, H*256] (with ger)
+ *             or both null; gel [n, H] is written as by gts_gat_bwd_src_f32.  max_degree: the largest out-degree (or -1:
+ *             unknown); with rows of at most one 8-edge chunk (<= 8) the weight pass takes a faster form, same values.
+ * workspace >= gts_gat_cluster_workspace(n_clusters, max_rows, loc_words, heads, backward) bytes. */
+int64_t gts_gat_cluster_workspace(int64_t n_clusters, int32_t max_rows, int32_t loc_words, int64_t heads, int32_t backward);
+int32_t gts_gat_attn_f32(const int32_t* indptr, const int32_t* indices, const float* el, const float* er,
+                         float negative_slope, float* attn, int64_t n, int64_t heads, int64_t max_degree, void* stream);
+int32_t gts_gat_fwd_cluster_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rec, int64_t n_clusters,
+                                int32_t max_rows, int32_t max_srcs, int32_t loc_words, int32_t tagged, const float* ft,
+                                const float* el, const float* er, float negative_slope, const float* bias,
+                                int32_t activation, float* out, float* attn, float* workspace, int64_t workspace_bytes,
+                                int64_t n, int64_t heads, int64_t dim, int64_t max_degree, void* stream);
+int32_t gts_gat_bwd_src_cluster_f32(const int32_t* t_indptr, const int32_t* t_pos, const int32_t* rec, int64_t n_clusters,
+                                    int32_t max_rows, int32_t max_srcs, int32_t loc_words, int32_t tagged,
+                                    const float* attn, const float* ge, const float* gout, const float* attn_lr,
+                                    const float* ger, float* gft, float* gel, float* workspace, int64_t workspace_bytes,
+                                    int64_t n, int64_t heads, int64_t dim, int64_t max_degree, void* stream);
+
 /* ---- K12: node -> voxel projection ----------------------------------------------------
  * Replaces data_processing/graph_io.py:21-24 (project_nodes_to_img) and
  * scripts/generate_gnn_predictions.py:55-61 (save_voxel_logits):
@@ -392,6 +418,7 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
                                     instantiation) instead of the compile-time epilogues of the layer-stack launches (A/B runs) */
 #define GTS_OPT_CLUSTER_STREAMING 8 /* clustered K1 / K2: bit 0 = non-temporal stores of out / gx; -1 = per-kernel default */
 #define GTS_OPT_GAT_WALK 14          /* K5-K8: 1 = walk the (node, head) rows head-major (default), 0 = node-major */
+#define GTS_OPT_GAT_CLUSTER_WAVES 15 /* clustered GAT aggregation: waves per persistent workgroup (0 = default 12; up to 16) */
 #define GTS_OPT_PANEL_ROWS 13        /* K11 direct-to-fragment panels: rows per panel, 0 = automatic among 240 / 192 / 144 */
 #define GTS_OPT_CLUSTER_KERNEL 9     /* clustered K1 / K2: 0 = persistent streaming workgroups (default), 1 = one workgroup per unit,
                                         2 = persistent workgroups with loader waves feeding a ring of slots to consumer waves */

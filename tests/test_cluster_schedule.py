@@ -134,3 +134,15 @@ def test_any_graph_any_limits_exact_cover(n, e, seed, rows, srcs):
             assert deg.max() > srcs or (which == "out" and g.t_slot.max() > 255)
         else:
             _check_cover(g, which, s)
+
+
+def test_gat_schedules_use_their_own_limits_and_carry_no_tags():
+    g = synth.lattice_graph((9, 8, 7))
+    for which in ("gat_in", "gat_out"):
+        s = g.cluster_schedule(which)
+        assert s is not None and not s.tagged and s.limits == schedule.limits(which) == (32, 64, 256)
+        rows = np.concatenate([c[0] for c in s.decode()])
+        assert np.array_equal(np.sort(rows), np.arange(g.n))            # an exact cover of the rows
+    assert g.cluster_schedule("gat_out") is not g.cluster_schedule("out")
+    dense = synth.geometric_graph(n=600, k=12, seed=1)                   # rows of two 8-edge chunks: the plain kernels keep them
+    assert dense.cluster_schedule("gat_in") is None
