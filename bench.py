@@ -477,6 +477,17 @@ def main():
                             for k, v in kinds.items()},
                 "sample": sample}
         # --- the HBM-bound kernels of the path: fraction from COMPULSORY bytes (each array once)
+        # what the events of an entry bracket: one library call = these kernels (clustered form when the graph has a schedule)
+        calls = {
+            "spmm_max_fwd_f256": "gts_spmm_max_fwd_cluster_f32: spmm_cluster_stream_kernel<fwd> (from 100 000 rows), else gts_spmm_max_fwd_f32",
+            "spmm_max_bwd_f256": "gts_spmm_max_bwd_cluster_f32: spmm_cluster_stream_kernel<bwd>, else gts_spmm_max_bwd_f32",
+            "gat_fwd": "gts_gat_fwd_cluster_f32: gat_weights_one_chunk_kernel (edge softmax) + gat_cluster_stream_kernel<fwd>, "
+                       "else gts_gat_fwd_f32",
+            "gat_bwd_edge": "gts_gat_bwd_edge_f32: gat_bwd_edge_kernel",
+            "gat_bwd_src": "gts_gat_bwd_src_cluster_f32: gat_weights_one_chunk_kernel + gat_cluster_stream_kernel<bwd>, "
+                           "else gts_gat_bwd_src_f32",
+            "project_rows": "gts_project_rows_i16: project_rows_kernel",
+        }
         hbm = []
         for name in cfg["hbm_kernels"]:
             s = timers.summary(name)
@@ -485,10 +496,11 @@ def main():
             us = 1e3 * s["total_ms"] / s["launches"]
             need = compulsory_bytes(name, n_b, e_b, arg_b)
             alg = algorithmic_bytes(name, n_b, e_b, arg_b)
-            traffic, source = from_profile(f"pmc_traffic{'_' + tag[:-1] if tag else ''}.json", name + "_bytes_per_launch")
+            pmc_file = "pmc_traffic_c3.json" if args.config == "c3" else f"pmc_traffic{'_' + tag[:-1] if tag else ''}.json"
+            traffic, source = from_profile(pmc_file, name + "_bytes_per_launch")
             rocprof_us, rsource = from_profile("rocprof_kernel_avg.json", (tag or "") + name + "_avg_us")
             gbs = need / (us * 1e-6) / 1e9
-            hbm.append({"bound": "hbm", "kernel": name, "model": "compulsory bytes: every input/output array once",
+            hbm.append({"bound": "hbm", "kernel": name, "call": calls.get(name), "model": "compulsory bytes: every input/output array once",
                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "compulsory_bytes_per_launch": need,
                         "traffic": traffic, "traffic_source": source,

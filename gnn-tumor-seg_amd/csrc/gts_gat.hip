@@ -33,6 +33,20 @@ __device__ __forceinline__ float group_sum(float x) {
   return x;
 }
 
+// The dot products of the backward's edge pass: over a whole wave the two halves of the row are reduced first (16, 8, 4, 2, 1)
+// and added last (32) — the clustered edge pass (gts_gat_cluster.hip) computes a column half per unit of work and adds
+// the two half sums in its finishing pass: the same tree, the same bits.
+template <int LPR>
+__device__ __forceinline__ float dot_lanes(float x) {
+  if constexpr (LPR == kWave) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) x += __shfl_xor(x, m, kWave);
+    return x + __shfl_xor(x, 32, kWave);
+  } else {
+    return group_sum<LPR>(x);
+  }
+}
+
 template <int LPR>
 __device__ __forceinline__ float group_max(float x) {
 #pragma unroll
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(
             }
           }
 #pragma unroll
-          for (int j = 0; j < CNT; ++j) part[j] = group_sum<LPR>(part[j]);
+          for (int j = 0; j < CNT; ++j) part[j] = dot_lanes<LPR>(part[j]);
 #pragma unroll
           for (int j = 0; j < CNT; ++j) {
             dot_sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_l), k0 + j)) * part[j];
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(
           }
         }
 #pragma unroll
-        for (int j = 0; j < CNT; ++j) part[j] = group_sum<LPR>(part[j]);
+        for (int j = 0; j < CNT; ++j) part[j] = dot_lanes<LPR>(part[j]);
 #pragma unroll
         for (int j = 0; j < CNT; ++j) {
           const size_t pos = static_cast<size_t>(k + j) * heads + h;

@@ -138,7 +138,10 @@ __global__ __launch_bounds__(kBlock) void gat_weights_one_chunk_kernel(const int
   const bool mine = k < deg;
   const size_t at = static_cast<size_t>(row) * heads;
   const size_t edge = mine ? static_cast<size_t>(BWD ? indices_or_pos[beg + k] : beg + k) * heads : 0;   // this lane's row of attn / ge
-  const size_t src = (!BWD && mine) ? static_cast<size_t>(indices_or_pos[beg + k]) * heads : 0;           // ... and of el
+  // the edge's source id out of the record itself (its position byte -> the cluster's neighbour list): the el fetch then waits for
+  // the record only, not for indptr -> indices
+  const int at_src = mine ? reinterpret_cast<const uint8_t*>(r + layout.loc)[c0 * 8 + k] : 0;
+  const size_t src = (!BWD && mine) ? static_cast<size_t>(r[layout.srcs + at_src]) * heads : 0;           // ... and of el
   float* block = side + static_cast<size_t>(c) * heads * side_floats;
   const int base = (threadIdx.x & (kWave - 1)) & ~7;
 #pragma unroll 4
@@ -169,12 +172,59 @@ __global__ __launch_bounds__(kBlock) void gat_weights_one_chunk_kernel(const int
   }
 }
 
+// Step 2 of the clustered edge pass (rows of one 8-edge chunk): the two half dot products of every edge are added (the last
+// step of gat_bwd_edge_kernel's dot_lanes), then the row's closing formula exactly as gat_bwd_edge_kernel writes it:
+//   ge_k = a_k (ga_k - sum_j a_j ga_j) leaky'(el[src_k] + er[v]),  ger[v, h] = sum_k ge_k   (sums in edge order).
+// Eight lanes per (cluster, row slot), heads inside, in the order of the records.
+__global__ __launch_bounds__(kBlock) void gat_edge_finish_kernel(const int32_t* __restrict__ rec, RecLayout layout, int n_clusters, int max_rows,
+                                                                 int heads, const int32_t* __restrict__ indptr,
+                                                                 const int32_t* __restrict__ indices, const float* __restrict__ el,
+                                                                 const float* __restrict__ er, const float* __restrict__ attn, float slope,
+                                                                 const float* __restrict__ halves, float* __restrict__ ge,
+                                                                 float* __restrict__ ger, int chunk_slots) {
+  const unsigned idx = blockIdx.x * static_cast<unsigned>(kBlock) + threadIdx.x;   // < 2^31 (host-checked)
+  const int k = static_cast<int>(idx & 7);
+  const unsigned grp = idx >> 3;
+  const unsigned c = grp / static_cast<unsigned>(max_rows);
+  const int j = static_cast<int>(grp - c * max_rows);
+  const int32_t* r = rec + static_cast<size_t>(c < static_cast<unsigned>(n_clusters) ? c : 0u) * layout.words;
+  const bool live = c < static_cast<unsigned>(n_clusters) && j < r[0];
+  const int row = live ? r[layout.rows + j] : 0;
+  const uint32_t info = live ? static_cast<uint32_t>(r[layout.eoff + j]) : 0u;
+  const int c0 = info & 0xFFFF, deg = info >> 16;          // deg <= 8 (host-checked)
+  const int beg = live ? indptr[row] : 0;
+  const bool mine = k < deg;
+  const size_t at = static_cast<size_t>(row) * heads;
+  const size_t edge = mine ? static_cast<size_t>(beg + k) * heads : 0;
+  const int at_src = mine ? reinterpret_cast<const uint8_t*>(r + layout.loc)[c0 * 8 + k] : 0;   // source id out of the record (see above)
+  const size_t src = mine ? static_cast<size_t>(r[layout.srcs + at_src]) * heads : 0;
+  const size_t half_stride = static_cast<size_t>(n_clusters) * heads * chunk_slots * 8;
+  const int base = (threadIdx.x & (kWave - 1)) & ~7;
+#pragma unroll 4
+  for (int h = 0; h < heads; ++h) {
+    const size_t slot = (static_cast<size_t>(c) * heads + h) * chunk_slots * 8 + c0 * 8 + k;
+    const float ga = mine ? halves[slot] + halves[half_stride + slot] : 0.0f;
+    const float a_l = mine ? attn[edge + h] : 0.0f;
+    const float pre = mine ? el[src + h] + er[at + h] : 0.0f;
+    float dot_sum = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dot_sum += __shfl(a_l, base + q, kWave) * __shfl(ga, base + q, kWave);   // lanes past the row's end: + 0 * 0
+    const float g_e = mine ? a_l * (ga - dot_sum) * (pre > 0.0f ? 1.0f : slope) : 0.0f;
+    if (mine) ge[edge + h] = g_e;
+    float ger_acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ger_acc += __shfl(g_e, base + q, kWave);
+    if (live && k == 0) ger[at + h] = ger_acc;
+  }
+}
+
 // ---- the persistent streaming kernel ----------------------------------------------------------------------------
 struct GatClusterArgs {
   const int32_t* rec;      // [n_clusters][layout.words]
   RecLayout layout;
   int n_clusters, max_srcs;
-  const float* table;      // forward: ft [N, H, 256];  backward: g_pre [N, H, 256]
+  const float* table;      // forward: ft [N, H, 256];  source pass: g_pre [N, H, 256];  edge pass: ft
+  const float* own;        // edge pass: g_pre [N, H, 256] (every row's own slice, staged behind the neighbours')
   const float* side;       // gat_arrange_kernel's blocks
   const float* vec;        // forward: bias [H, 256] or null;  backward: attn_l | attn_r [2][H, 256] or null
   float* out;              // forward: out [N, H, 256];  backward: gft
@@ -182,6 +232,7 @@ struct GatClusterArgs {
   int heads, act;
   int side_floats, chunk_slots, side_pieces;
   int rec_bytes, side_slot_bytes, image_bytes;   // LDS: 3 record slots | 3 side slots | 3 vector slots of 1 KiB | 2 images
+  int own_off;             // edge pass: byte offset of the own-row section inside an image
 };
 
 // the rows of one unit out of LDS: half a wave per row, 16 B per lane; acc += w_k * slice_k in slot order, one
@@ -245,13 +296,72 @@ __device__ __forceinline__ int reduce_wsum_rows(const GatClusterArgs& a, const i
   return trips;
 }
 
+// Edge pass of the backward (K8, step 1): ga_k = <g_pre[v, h, :], ft[src_k, h, :]> for every in-edge.  A unit holds one column
+// half, so it produces HALF dot products: each lane adds its four products in order, the 32 lanes of the row's half wave
+// combine with the butterfly 16, 8, 4, 2, 1 — the first five steps of gat_bwd_edge_kernel's `dot_lanes` (gts_gat.hip), whose
+// last step (x + x^32) adds the two halves: gat_edge_finish_kernel does exactly that addition, so ga has the plain kernel's
+// bits.  Partials go to side[part][cluster][head][chunk][8] (the record's chunk order): 32 B per row and chunk.
+__device__ __forceinline__ int reduce_edge_rows(const GatClusterArgs& a, const int32_t* l_rec, const unsigned char* image,
+                                                float* out_block, int first, int step) {
+  const int lane = threadIdx.x & (kWave - 1), half = lane >> 5, hl = lane & 31;
+  const int n_rows = l_rec[0];
+  const uint32_t* info = reinterpret_cast<const uint32_t*>(l_rec + a.layout.eoff);
+  const uint2* loc = reinterpret_cast<const uint2*>(l_rec + a.layout.loc);
+  const unsigned char* mine = image + hl * 16;
+  int stores = 0;
+  for (int j0 = 2 * first; j0 < n_rows; j0 += 2 * step) {
+    const int j = j0 + half;
+    const bool have = j < n_rows;
+    const uint32_t ri = have ? info[j] : 0u;
+    const int c0 = ri & 0xFFFF, deg = ri >> 16;
+    const int deg_w = max(__builtin_amdgcn_readlane(deg, 0), __builtin_amdgcn_readlane(deg, 32));
+    const float4 g = *reinterpret_cast<const float4*>(image + a.own_off + (have ? j : 0) * kHalfBytes + hl * 16);
+    for (int c = 0; 8 * c < deg_w; ++c, ++stores) {
+      const bool mine_too = 8 * c < deg;
+      const uint2 w = loc[mine_too ? c0 + c : c0];
+      float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for_count(min(8, deg_w - 8 * c), [&](auto cnt_c) {
+        constexpr int CNT = decltype(cnt_c)::value;
+        float4 val[CNT];
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) val[q] = *reinterpret_cast<const float4*>(mine + chunk_byte(w, q) * kHalfBytes);
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+          part[q] += g.x * val[q].x;
+          part[q] += g.y * val[q].y;
+          part[q] += g.z * val[q].z;
+          part[q] += g.w * val[q].w;
+        }
+      });
+      // The butterfly 16, 8, 4, 2, 1 of all eight sums at once: at each of the first three steps a lane keeps the half of
+      // its values its lane bit selects and hands the other half to its partner, which adds them to the ones IT keeps —
+      // every sum still meets the same partners in the same order (9 cross-lane moves instead of 40; fp32 addition
+      // commutes).  Lane hl ends up with the sum of edge 4 (hl / 16 % 2) + 2 (hl / 8 % 2) + hl / 4 % 2.
+      const bool b16 = (hl & 16) != 0, b8 = (hl & 8) != 0, b4 = (hl & 4) != 0;
+      float k4[4], k2[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) k4[i] = (b16 ? part[i + 4] : part[i]) + __shfl_xor(b16 ? part[i] : part[i + 4], 16, kWave);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) k2[i] = (b8 ? k4[i + 2] : k4[i]) + __shfl_xor(b8 ? k4[i] : k4[i + 2], 8, kWave);
+      float k1 = (b4 ? k2[1] : k2[0]) + __shfl_xor(b4 ? k2[0] : k2[1], 4, kWave);
+      k1 += __shfl_xor(k1, 2, kWave);
+      k1 += __shfl_xor(k1, 1, kWave);
+      const int q_mine = (b16 ? 4 : 0) + (b8 ? 2 : 0) + (b4 ? 1 : 0);
+      if (have && mine_too && (hl & 3) == 0) out_block[(c0 + c) * 8 + q_mine] = k1;
+    }
+  }
+  return stores;
+}
+
 // gridDim.x is a multiple of 8: the workgroups with blockIdx % 8 == x (one XCD under round-robin placement; speed only)
 // share the x-th eighth of the CLUSTERS and walk its units sub-unit by sub-unit (all clusters of the span for head 0 /
 // left half, then head 0 / right half, ...), round-robin: the units in flight on an XCD at one time are the same
 // column half of neighbouring clusters, whose halo slices meet in its L2.
 // MINW = 8: up to 16 waves per workgroup at <= 64 registers; 6: up to 12 waves at <= 80 (two workgroups per CU either way)
-template <bool BWD, int MINW>
+// MODE 0: forward aggregation;  1: source pass of the backward;  2: edge pass of the backward (half dot products)
+template <int MODE, int MINW>
 __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const GatClusterArgs a) {
+  constexpr bool BWD = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -267,11 +377,12 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
   const int rec_pieces = a.rec_bytes / 1024;
   unsigned char* side_slots = lds + 3 * a.rec_bytes;
   unsigned char* vec_slots = side_slots + 3 * a.side_slot_bytes;
-  unsigned char* images = vec_slots + 3 * 1024;
+  unsigned char* images = MODE == 2 ? lds + 3 * a.rec_bytes : vec_slots + 3 * 1024;   // the edge pass keeps no weight / vector slots
   const RawDma rr(a.rec, static_cast<unsigned>(a.n_clusters) * words * 4u);
   const RawDma rt(a.table, a.table_bytes);
   const RawDma rs(a.side, a.side_bytes);
   const RawDma rv(a.vec, a.vec != nullptr ? a.vec_bytes : 0);
+  const RawDma ro(MODE == 2 ? a.own : a.table, a.table_bytes);
   auto unit = [&](int t, int* sub) {        // t-th unit of this workgroup: its cluster, and which (head, half) of it
     const unsigned i = static_cast<unsigned>(jw) + static_cast<unsigned>(t) * per_xcd;   // < 2^31 (host-checked)
     const unsigned s = i / static_cast<unsigned>(span);
@@ -285,6 +396,8 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
     if (wave < rec_pieces) {
       const int word = 256 * wave + 4 * lane;
       rr(lds + slot * a.rec_bytes + 1024 * wave, word < words ? (cluster * static_cast<unsigned>(words) + word) * 4u : 0xFFFFFFF0u);
+    } else if (MODE == 2) {
+      // the edge pass fetches nothing but the record
     } else if (wave < rec_pieces + a.side_pieces) {
       const int p = wave - rec_pieces, word = 256 * p + 4 * lane;
       const unsigned base = (cluster * static_cast<unsigned>(a.heads) + static_cast<unsigned>(sub >> 1)) * static_cast<unsigned>(a.side_floats);
@@ -312,6 +425,15 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
       const int s0 = __builtin_amdgcn_readlane(ids, 2 * k), s1 = __builtin_amdgcn_readlane(ids, 2 * k + 1);
       rt(image + i * kHalfBytes, static_cast<unsigned>(lane < 32 ? s0 : s1) * row_bytes + col);
     }
+    if constexpr (MODE == 2) {              // ... and of its rows' own gradient slices, the same way out of the other table
+      const int n_rows = l_rec[0];
+      const int32_t own_ids = l_rec[a.layout.rows + min(2 * (wave + n_waves * (lane >> 1)) + (lane & 1), n_rows - 1)];
+      int k2 = 0;
+      for (int i = 2 * wave; i < n_rows; i += 2 * n_waves, ++k2) {
+        const int s0 = __builtin_amdgcn_readlane(own_ids, 2 * k2), s1 = __builtin_amdgcn_readlane(own_ids, 2 * k2 + 1);
+        ro(image + a.own_off + i * kHalfBytes, static_cast<unsigned>(lane < 32 ? s0 : s1) * row_bytes + col);
+      }
+    }
   };
 
   // Per iteration a wave issues, in this order: [record / weights / vectors of unit it + 2] [gathers of unit it + 1] [stores
@@ -330,9 +452,18 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
     int sub;
     unit(it, &sub);
     const int slot = it % 3;
-    stores = reduce_wsum_rows<BWD>(a, reinterpret_cast<const int32_t*>(lds + slot * a.rec_bytes), images + (it & 1) * a.image_bytes,
-                                   reinterpret_cast<const float*>(side_slots + slot * a.side_slot_bytes),
-                                   reinterpret_cast<const float*>(vec_slots + slot * 1024), sub, wave, n_waves);
+    if constexpr (MODE == 2) {
+      const int cluster = unit(it, &sub);
+      // partial dot products of this (cluster, head) for column half `sub & 1`
+      float* block = a.out + (static_cast<size_t>(sub & 1) * a.n_clusters * a.heads + static_cast<size_t>(cluster) * a.heads + (sub >> 1)) *
+                                 (a.chunk_slots * 8);
+      stores = reduce_edge_rows(a, reinterpret_cast<const int32_t*>(lds + slot * a.rec_bytes), images + (it & 1) * a.image_bytes, block,
+                                wave, n_waves);
+    } else {
+      stores = reduce_wsum_rows<BWD>(a, reinterpret_cast<const int32_t*>(lds + slot * a.rec_bytes), images + (it & 1) * a.image_bytes,
+                                     reinterpret_cast<const float*>(side_slots + slot * a.side_slot_bytes),
+                                     reinterpret_cast<const float*>(vec_slots + slot * 1024), sub, wave, n_waves);
+    }
   }
 }
 
@@ -340,47 +471,48 @@ struct GatPlan {
   int chunk_slots, side_floats, side_pieces, rec_bytes, side_slot_bytes, image_bytes, waves;
   int64_t wg_lds;
 };
-inline GatPlan gat_plan(int max_rows, int max_srcs, int loc_words, bool tagged, bool bwd) {
+inline GatPlan gat_plan(int max_rows, int max_srcs, int loc_words, bool tagged, bool bwd, bool edge = false) {
   GatPlan p;
   p.chunk_slots = loc_words / 2;
   p.side_floats = p.chunk_slots * 8 + (bwd ? max_rows * 2 : 0);
   p.side_pieces = (p.side_floats + 255) / 256;
   p.rec_bytes = 1024 * ((rec_layout(max_rows, max_srcs, loc_words, tagged).words + 255) / 256);
   p.side_slot_bytes = 1024 * p.side_pieces;
-  p.image_bytes = ((max_srcs + 1) & ~1) * kHalfBytes;
+  p.image_bytes = (((max_srcs + 1) & ~1) + (edge ? (max_rows + 1) & ~1 : 0)) * kHalfBytes;   // edge pass: the rows' own slices behind the neighbours'
   p.waves = g_gat_cluster_waves > 0 ? std::max(4, std::min(16, g_gat_cluster_waves)) : 12;
-  p.wg_lds = 3LL * p.rec_bytes + 3LL * p.side_slot_bytes + 3 * 1024 + 2LL * p.image_bytes;
+  p.wg_lds = 3LL * p.rec_bytes + (edge ? 0 : 3LL * p.side_slot_bytes + 3 * 1024) + 2LL * p.image_bytes;
   return p;
 }
 
 inline bool bad_gat_cluster(int64_t n_clusters, int32_t max_rows, int32_t max_srcs, int32_t loc_words, bool tagged, bool bwd,
-                            int64_t n, int64_t heads, int64_t dim) {
+                            int64_t n, int64_t heads, int64_t dim, bool edge = false) {
   if (n_clusters < 0 || n_clusters >= (1 << 28) || max_rows < 1 || max_srcs < 1 || max_srcs > 256 || loc_words < 2 ||
       loc_words % 4 != 0 || n < 0 || heads < 1 || heads > 64 || dim != kF)
     return true;
   if (n * heads * kF * 4 >= (1LL << 32) || n_clusters * heads * 2 + 4096 >= (1LL << 31)) return true;   // 32-bit byte offsets into the table; unit ids
   if (n_clusters * rec_layout(max_rows, max_srcs, loc_words, tagged).words * 4 >= (1LL << 32)) return true;
   if (n_clusters * max_rows * 8 + 4096 >= (1LL << 31)) return true;                               // thread ids of the weight pass
-  const GatPlan p = gat_plan(max_rows, max_srcs, loc_words, tagged, bwd);
-  if (n_clusters * heads * p.side_floats * 4 >= (1LL << 32)) return true;     // ... and into the weight blocks
+  const GatPlan p = gat_plan(max_rows, max_srcs, loc_words, tagged, bwd, edge);
+  if (n_clusters * heads * p.side_floats * 4 * (edge ? 2 : 1) >= (1LL << 32)) return true;     // ... and into the weight blocks
   if (rec_layout(max_rows, max_srcs, loc_words, tagged).words > 512 || p.wg_lds > kMaxLds) return true;
   if (p.rec_bytes / 1024 + p.side_pieces + 1 > p.waves || max_srcs > 64 * p.waves || max_rows > 2 * 64) return true;
   return false;
 }
 
-template <bool BWD>
+template <int MODE>
 int launch_gat_cluster(GatClusterArgs a, const GatPlan& p, hipStream_t st) {
   a.side_floats = p.side_floats, a.chunk_slots = p.chunk_slots, a.side_pieces = p.side_pieces;
   a.rec_bytes = p.rec_bytes, a.side_slot_bytes = p.side_slot_bytes, a.image_bytes = p.image_bytes;
+  a.own_off = ((a.max_srcs + 1) & ~1) * kHalfBytes;
   const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({g_cluster_per_cu > 0 ? g_cluster_per_cu : 2, kMaxLds / p.wg_lds,
                                                                                static_cast<int64_t>(32 / p.waves)})));
   const int64_t units = 2LL * a.heads * a.n_clusters;
   int64_t grid = static_cast<int64_t>(device_cus()) * per_cu;
   grid = std::max<int64_t>(8, std::min(grid, (units + 7) / 8 * 8)) / 8 * 8;
-  static const bool once = (allow_big_lds(gat_cluster_stream_kernel<BWD, 6>), allow_big_lds(gat_cluster_stream_kernel<BWD, 8>), true);
+  static const bool once = (allow_big_lds(gat_cluster_stream_kernel<MODE, 6>), allow_big_lds(gat_cluster_stream_kernel<MODE, 8>), true);
   (void)once;
-  if (p.waves > 12) gat_cluster_stream_kernel<BWD, 8><<<dim3(static_cast<unsigned>(grid)), p.waves * kWave, p.wg_lds, st>>>(a);
-  else gat_cluster_stream_kernel<BWD, 6><<<dim3(static_cast<unsigned>(grid)), p.waves * kWave, p.wg_lds, st>>>(a);
+  if (p.waves > 12) gat_cluster_stream_kernel<MODE, 8><<<dim3(static_cast<unsigned>(grid)), p.waves * kWave, p.wg_lds, st>>>(a);
+  else gat_cluster_stream_kernel<MODE, 6><<<dim3(static_cast<unsigned>(grid)), p.waves * kWave, p.wg_lds, st>>>(a);
   return launch_status();
 }
 
@@ -459,7 +591,7 @@ extern "C" int32_t gts_gat_fwd_cluster_f32(const int32_t* indptr, const int32_t*
   a.side_bytes = static_cast<unsigned>(n_clusters * heads * p.side_floats * 4);
   a.vec_bytes = static_cast<unsigned>(heads * kF * 4);
   a.heads = nh, a.act = activation;
-  return launch_gat_cluster<false>(a, p, st);
+  return launch_gat_cluster<0>(a, p, st);
 }
 
 extern "C" int32_t gts_gat_bwd_src_cluster_f32(const int32_t* t_indptr, const int32_t* t_pos, const int32_t* rec, int64_t n_clusters,
@@ -494,5 +626,34 @@ extern "C" int32_t gts_gat_bwd_src_cluster_f32(const int32_t* t_indptr, const in
   a.side_bytes = static_cast<unsigned>(n_clusters * heads * p.side_floats * 4);
   a.vec_bytes = static_cast<unsigned>(2 * heads * kF * 4);
   a.heads = nh, a.act = 0;
-  return launch_gat_cluster<true>(a, p, st);
+  return launch_gat_cluster<1>(a, p, st);
+}
+
+extern "C" int32_t gts_gat_bwd_edge_cluster_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rec, int64_t n_clusters,
+                                                int32_t max_rows, int32_t max_srcs, int32_t loc_words, int32_t tagged, const float* ft,
+                                                const float* el, const float* er, const float* attn, const float* gout,
+                                                float negative_slope, float* ge, float* ger, float* workspace, int64_t workspace_bytes,
+                                                int64_t n, int64_t heads, int64_t dim, int64_t max_degree, void* stream) {
+  using namespace gts;
+  if (!indptr || !rec || !ft || !el || !er || !attn || !gout || !ge || !ger || !workspace) return GTS_ERR_NULL;
+  if (bad_gat_cluster(n_clusters, max_rows, max_srcs, loc_words, tagged != 0, false, n, heads, dim, true)) return GTS_ERR_SHAPE;
+  if (max_degree < 0 || max_degree > 8) return GTS_ERR_SHAPE;     // rows of one 8-edge chunk (the finishing pass)
+  if (workspace_bytes < 2 * gts_gat_cluster_workspace(n_clusters, max_rows, loc_words, heads, 0)) return GTS_ERR_SHAPE;
+  if (n == 0 || n_clusters == 0) return GTS_OK;
+  if (!indices && max_degree > 0) return GTS_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const GatPlan p = gat_plan(max_rows, max_srcs, loc_words, tagged != 0, false, true);
+  const RecLayout lay = rec_layout(max_rows, max_srcs, loc_words, tagged != 0);
+  GatClusterArgs a{};
+  a.rec = rec, a.layout = lay, a.n_clusters = static_cast<int>(n_clusters), a.max_srcs = max_srcs;
+  a.table = ft, a.own = gout, a.out = workspace;
+  a.table_bytes = static_cast<unsigned>(n * heads * kF * 4);
+  a.heads = static_cast<int>(heads);
+  int rc = launch_gat_cluster<2>(a, p, st);
+  if (rc != GTS_OK) return rc;
+  const int64_t threads = n_clusters * max_rows * 8;
+  gat_edge_finish_kernel<<<static_cast<unsigned>((threads + kBlock - 1) / kBlock), kBlock, 0, st>>>(
+      rec, lay, static_cast<int>(n_clusters), max_rows, static_cast<int>(heads), indptr, indices, el, er, attn, negative_slope, workspace, ge,
+      ger, p.chunk_slots);
+  return launch_status();
 }

@@ -10,7 +10,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgts_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "gts_hip.h")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -38,6 +38,8 @@ SIGNATURES = {
     "gts_gat_attn_f32": [_p, _p, _p, _p, _f32, _p, _i64, _i64, _i64, _p],
     "gts_gat_fwd_cluster_f32": [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _f32, _p, _i32, _p, _p, _p, _i64,
                                 _i64, _i64, _i64, _i64, _p],
+    "gts_gat_bwd_edge_cluster_f32": [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _f32, _p, _p, _p, _i64,
+                                     _i64, _i64, _i64, _i64, _p],
     "gts_gat_bwd_src_cluster_f32": [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i64,
                                     _i64, _i64, _i64, _i64, _p],
     "gts_gat_param_grad_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],

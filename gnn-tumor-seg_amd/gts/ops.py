@@ -239,7 +239,7 @@ def _gat_cluster_schedule(g, which, n, heads, dim):
 
     if not schedule.ENABLED_GAT or dim != 256 or n < schedule.MIN_ROWS_GAT or n * heads * 1024 >= 2 ** 32 or heads > 64:
         return None
-    if which == "gat_in" and g.max_in_degree > 64:
+    if which.endswith("in") and g.max_in_degree > 64:
         return None
     return g.dev_schedule(which)
 
@@ -260,8 +260,18 @@ def _gat_bwd(g, ft, el, er, attn, gout, slope, attn_l=None, attn_r=None):
     ge = torch.empty_like(attn)
     ger = torch.empty_like(er)
     wide = h * dim >= 256
-    edge = lambda: lib.gts_gat_bwd_edge_f32(ptr(d.indptr), ptr(d.indices), ptr(ft), ptr(el), ptr(er), ptr(attn),   # noqa: E731
-                                            ptr(gout), float(slope), ptr(ge), ptr(ger), n, h, dim, current_stream())
+    es = _gat_cluster_schedule(g, "gat_edge_in", n, h, dim) if g.max_in_degree <= 8 else None
+    if es is not None:
+        hs = es.host
+        nbytes = 2 * lib.gts_gat_cluster_workspace(hs.n_clusters, hs.limits[0], hs.loc_words, h, 0)
+        ws_e = _gat_ws(ft.device, nbytes)
+        edge = lambda: lib.gts_gat_bwd_edge_cluster_f32(      # noqa: E731
+            ptr(d.indptr), ptr(d.indices), ptr(es.packed), hs.n_clusters, hs.limits[0], hs.limits[1], hs.loc_words,
+            1 if hs.tagged else 0, ptr(ft), ptr(el), ptr(er), ptr(attn), ptr(gout), float(slope), ptr(ge), ptr(ger),
+            ptr(ws_e), nbytes, n, h, dim, g.max_in_degree, current_stream())
+    else:
+        edge = lambda: lib.gts_gat_bwd_edge_f32(ptr(d.indptr), ptr(d.indices), ptr(ft), ptr(el), ptr(er), ptr(attn),   # noqa: E731
+                                                ptr(gout), float(slope), ptr(ge), ptr(ger), n, h, dim, current_stream())
     check(_timed("gat_bwd_edge", edge) if wide else edge(), "gts_gat_bwd_edge_f32")
     gft = torch.empty_like(ft)
     gel = torch.empty_like(el)

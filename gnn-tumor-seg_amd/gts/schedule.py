@@ -30,7 +30,10 @@ from . import _lib
 # then about 39 KiB: four slots per persistent workgroup, one workgroup per CU.
 # 'gat_in' / 'gat_out': the GATConv aggregation over the in- / out-CSR (csrc/gts_gat_cluster.hip): its workgroups also hold three
 # weight blocks and three epilogue-vector slots, so the neighbour list is shorter (two workgroups of 78 KB per CU).
-_DEFAULT_LIMITS = {"in": (32, 76, 512), "out": (32, 60, 512), "gat_in": (32, 64, 256), "gat_out": (32, 64, 256)}
+# 'gat_edge_in': the edge pass of GATConv's backward stages the rows' own gradient slices behind the neighbours' (74 slices of
+# 512 B per image).
+_DEFAULT_LIMITS = {"in": (32, 76, 512), "out": (32, 60, 512), "gat_in": (32, 64, 256), "gat_out": (32, 64, 256),
+                   "gat_edge_in": (24, 50, 192)}
 # A schedule is used when it stages at most this share of the rows the plain kernel would fetch (one per edge).
 WORTHWHILE = float(os.environ.get("GTS_CLUSTER_WORTHWHILE", "0.6"))
 ENABLED = os.environ.get("GTS_CLUSTER_SPMM", "1") != "0"
@@ -59,7 +62,7 @@ def limits(which):
     env = os.environ.get("GTS_GAT_CLUSTER_LIMITS" if which.startswith("gat_") else "GTS_CLUSTER_LIMITS")
     if env:
         both = [tuple(int(v) for v in part.split(",")) for part in env.split(";")]
-        return both[0 if which.endswith("in") else 1]
+        return both[2 if which == "gat_edge_in" else 0 if which.endswith("in") else 1]
     return _DEFAULT_LIMITS[which]
 
 

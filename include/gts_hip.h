@@ -184,6 +184,14 @@ int32_t gts_gat_fwd_cluster_f32(const int32_t* indptr, const int32_t* indices, c
                                 const float* el, const float* er, float negative_slope, const float* bias,
                                 int32_t activation, float* out, float* attn, float* workspace, int64_t workspace_bytes,
                                 int64_t n, int64_t heads, int64_t dim, int64_t max_degree, void* stream);
+/* edge pass (step 1 of gts_gat_bwd_edge_f32's job, same ge [E, H] / ger [n, H] bit for bit): in-CSR + a schedule of the in-CSR whose
+ * images also hold the rows' own gradient slices; rows of one 8-edge chunk only (max_degree <= 8, else GTS_ERR_SHAPE).
+ * workspace >= 2 * gts_gat_cluster_workspace(n_clusters, max_rows, loc_words, heads, 0) bytes (the two half dot products). */
+int32_t gts_gat_bwd_edge_cluster_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rec, int64_t n_clusters,
+                                     int32_t max_rows, int32_t max_srcs, int32_t loc_words, int32_t tagged, const float* ft,
+                                     const float* el, const float* er, const float* attn, const float* gout,
+                                     float negative_slope, float* ge, float* ger, float* workspace, int64_t workspace_bytes,
+                                     int64_t n, int64_t heads, int64_t dim, int64_t max_degree, void* stream);
 int32_t gts_gat_bwd_src_cluster_f32(const int32_t* t_indptr, const int32_t* t_pos, const int32_t* rec, int64_t n_clusters,
                                     int32_t max_rows, int32_t max_srcs, int32_t loc_words, int32_t tagged,
                                     const float* attn, const float* ge, const float* gout, const float* attn_lr,

@@ -77,6 +77,8 @@ def test_attention_weights_alone_equal_the_fused_forward_kernels(max_degree):
 def test_clustered_gat_forward_and_source_pass_equal_the_plain_kernels_bit_for_bit(name, heads, bias, act):
     g = _graphs()[name]
     assert g.cluster_schedule("gat_in") is not None and g.cluster_schedule("gat_out") is not None
+    # the edge pass of the backward takes its clustered form on rows of one 8-edge chunk (both lattices, their batches)
+    assert (g.cluster_schedule("gat_edge_in") is not None) or g.max_in_degree > 8 or name == "batch"
     gd = g.to(DEV)
     ft, el, er = _inputs(g, heads, len(name))
     b = torch.randn(heads * 256, generator=torch.Generator().manual_seed(5)).to(DEV) if bias else None
@@ -102,6 +104,7 @@ def test_default_rules_pick_the_clustered_kernels_for_the_c3_batch_and_not_for_d
     big = gts.batch([synth.lattice_graph() for _ in range(2)]).to(DEV)
     assert ops._gat_cluster_schedule(big, "gat_in", big.n, 4, 256) is not None
     assert ops._gat_cluster_schedule(big, "gat_out", big.n, 4, 256) is not None
+    assert ops._gat_cluster_schedule(big, "gat_edge_in", big.n, 4, 256) is not None
     assert ops._gat_cluster_schedule(big, "gat_in", big.n, 4, 64) is None                      # D != 256
     small = synth.lattice_graph((9, 8, 7)).to(DEV)
     assert ops._gat_cluster_schedule(small, "gat_in", small.n, 4, 256) is None

@@ -15,9 +15,4 @@ hb = {e["kernel"]: (e.get("avg_launch_us"), e.get("frac")) for e in d.get("roofl
 print(sys.argv[2], d["value"], d["ms_per_step"], hb, flush=True)
 PY
 }
-run plain GTS_CLUSTER_GAT=0 && run default GTS_CLUSTER_GAT=1 && \
-run w10 GTS_OPTIONS=15=10 && run w14 GTS_OPTIONS=15=14 && \
-run l24_48 "GTS_GAT_CLUSTER_LIMITS=24,48,192;24,48,192" && \
-run l16_36_w8x4 "GTS_GAT_CLUSTER_LIMITS=16,36,128;16,36,128" GTS_OPTIONS=15=8,11=4 && \
-run l16_36_w10x3 "GTS_GAT_CLUSTER_LIMITS=16,36,128;16,36,128" GTS_OPTIONS=15=10,11=3 && \
-run l32_60 "GTS_GAT_CLUSTER_LIMITS=32,60,256;32,60,256"
+run plain GTS_CLUSTER_GAT=0 && run default GTS_CLUSTER_GAT=1

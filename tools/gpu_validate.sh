@@ -41,6 +41,9 @@ python tools/parse_pmc.py $OUT/pmc_fetch_b8 $OUT/pmc_write_b8 $OUT/pmc_traffic_b
 pmc FETCH_SIZE pmc_fetch_b32 "--graphs-per-gpu 32 --steps 2 --warmup 1 --blocks 1"
 pmc WRITE_SIZE pmc_write_b32 "--graphs-per-gpu 32 --steps 2 --warmup 1 --blocks 1"
 python tools/parse_pmc.py $OUT/pmc_fetch_b32 $OUT/pmc_write_b32 $OUT/pmc_traffic_b32.json | tail -12
+pmc FETCH_SIZE pmc_fetch_c3 "--config c3 --steps 2 --warmup 1 --blocks 1"
+pmc WRITE_SIZE pmc_write_c3 "--config c3 --steps 2 --warmup 1 --blocks 1"
+python tools/parse_pmc.py $OUT/pmc_fetch_c3 $OUT/pmc_write_c3 $OUT/pmc_traffic_c3.json | tail -16
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_aux -- python tools/measure_aux_kernels.py > $OUT/aux_kernels.jsonl 2> $OUT/aux_kernels.err
 rm -f $OUT/prof*/*/*kernel_trace.csv $OUT/pmc*/*/*kernel_trace.csv   # large; the stats files are what we keep
 echo done

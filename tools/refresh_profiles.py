@@ -26,7 +26,7 @@ def last_json_line(path):
 for name in ("c2", "c3", "c5", "c2_b8", "c2_b32", "real"):
     with open(f"{dst}/{rnd}_bench_{name}.json", "w") as fh:
         fh.write(last_json_line(f"{src}/bench_{name}.json") + "\n")
-for name in ("pmc_traffic.json", "pmc_traffic_b8.json", "pmc_traffic_b32.json"):
+for name in ("pmc_traffic.json", "pmc_traffic_b8.json", "pmc_traffic_b32.json", "pmc_traffic_c3.json"):
     shutil.copy(f"{src}/{name}", f"{dst}/{name}")
 shutil.copy(f"{src}/aux_kernels.jsonl", f"{dst}/{rnd}_aux_kernels.jsonl")
 shutil.copy(f"{src}/epoch_throughput.jsonl", f"{dst}/{rnd}_epoch_throughput.jsonl")
@@ -81,9 +81,16 @@ for tag, rows, label in (("", c2, "C2"), ("b8_", b8, "--config c4 (8 graphs per 
     if tag:
         avg[f"{tag}source"] = f"profiles/{rnd}_bench_c2_{tag[:-1]}_kernel_stats.csv ({label})"
 avg["c3_source"] = f"profiles/{rnd}_bench_c3_kernel_stats.csv (--config c3)"
-for key, needle in (("gat_fwd", ("gat_fwd_kernel<4, 64>",)), ("gat_bwd_edge", ("gat_bwd_edge_kernel<4",)),
-                    ("gat_bwd_src", ("gat_bwd_src_kernel<4",))):
-    hits = [n for n in c3 if needle[0] in n]
-    avg[f"{key}_avg_us"] = mean_us(c3, needle)[0] if hits else None
+# hidden-layer launches only (D = 256); the clustered form of a call = its weight pass + the streaming kernel
+for key, plain, clustered in (("gat_fwd", "gat_fwd_kernel<4, 64>", ("gat_cluster_stream_kernel<false", "gat_weights_one_chunk_kernel<false>")),
+                              ("gat_bwd_edge", "gat_bwd_edge_kernel<4, 64>", ()),
+                              ("gat_bwd_src", "gat_bwd_src_kernel<4, 64>", ("gat_cluster_stream_kernel<true", "gat_weights_one_chunk_kernel<true>"))):
+    parts = [(needle, mean_us(c3, (needle,))[0]) for needle in clustered if any(needle in n for n in c3)]
+    if parts:
+        avg[f"{key}_avg_us"], avg[f"{key}_form"] = round(sum(us for _, us in parts), 2), "clustered"
+        avg[f"{key}_kernels_us"] = {needle: us for needle, us in parts}
+    else:
+        avg[f"{key}_avg_us"] = mean_us(c3, (plain,))[0] if any(plain in n for n in c3) else None
+        avg[f"{key}_form"] = "plain"
 json.dump(avg, open(f"{dst}/rocprof_kernel_avg.json", "w"), indent=1)
 print(json.dumps(avg, indent=1))
