@@ -165,15 +165,20 @@ class GNN:
         return graph, features, up(labels, torch.int64)
 
     def _schedules_wanted(self, n_rows):
-        """Cluster row schedules ('in' / 'out') the training step of this network will ask the graph for: the
-        prefetch thread builds and uploads them with the batch instead of leaving that to the first kernel call."""
+        """Cluster row schedules the training step of this network will ask the graph for ('in' / 'out': the max-pool
+        reducers of SAGEConv-pool at 256 features; 'gat_*': GATConv at 256 features per head): the prefetch thread builds
+        and uploads them with the batch instead of leaving that to the first kernel call."""
         from gts import schedule
-        from gts.nn import SAGEConv
+        from gts.nn import GATConv, SAGEConv
 
-        if not schedule.ENABLED or not any(isinstance(m, SAGEConv) and m._aggre_type == "pool" and m._in_src_feats == 256
-                                           for m in self.net.modules()):
-            return ()
-        return ("out", "in") if n_rows >= schedule.MIN_ROWS_FORWARD else ("out",)
+        wanted = ()
+        if schedule.ENABLED and any(isinstance(m, SAGEConv) and m._aggre_type == "pool" and m._in_src_feats == 256
+                                    for m in self.net.modules()):
+            wanted += ("out", "in") if n_rows >= schedule.MIN_ROWS_FORWARD else ("out",)
+        if schedule.ENABLED_GAT and n_rows >= schedule.MIN_ROWS_GAT and any(
+                isinstance(m, GATConv) and m._out_feats == 256 for m in self.net.modules()):
+            wanted += ("gat_in", "gat_edge_in", "gat_out")
+        return wanted
 
     def _device_batches(self):
         """The loader's batches, already on the GPU, prepared one step ahead: a worker thread
