@@ -184,7 +184,7 @@ __device__ __forceinline__ void gather_winner_halves(const Dma& dma, int part, u
 // only) share the x-th eighth of the units and take them round-robin.  LDS: three record slots, two images.
 // WHATIF != 0 only in the timing experiments of tools/diag (wrong results): 1 = no row gathers, 2 = no reduction and
 // no stores, 3 = no stores, 4 = stores without the reduction (K1).
-template <bool BWD, int ARGB, int WHATIF = 0>
+template <bool BWD, int ARGB, int WHATIF = 0, int DEPTH = 1>
 // Two workgroups per CU: 16 waves each for K1 (<= 64 registers), 12 for K2 (its 68 registers: 6 waves per SIMD).  With 8 waves
 // the reduction of a unit is latency-bound (lattice, 8 graphs: 67.6 / 72.2 us against 63.9 / 67.8; k-NN graphs of mean
 // degree 7 - 10: 78 - 144 us against 65 - 96, profiles/r03_cluster_other_graphs.log).
@@ -203,7 +203,8 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
   const int rec_bytes = 1024 * pieces, image_bytes = a.slot_bytes - a.image_off;
   // gathers run `depth` units ahead of the reduction: depth + 1 images, depth + 2 record slots (the record of the unit whose
   // gathers are issued next is fetched one iteration before that)
-  const int depth = a.ring, n_images = depth + 1, n_recs = depth + 2;
+  // (DEPTH is a template constant: with run-time slot counts the K1 form spills a register and both forms lose 8 - 10 %)
+  constexpr int depth = DEPTH, n_images = DEPTH + 1, n_recs = DEPTH + 2;
   unsigned char* images = lds + n_recs * rec_bytes;
   const RawDma rr(a.rec, static_cast<unsigned>(a.n_clusters) * words * 4u);
   const RawDma rt(a.table, a.table_bytes);
@@ -271,9 +272,13 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
     lap(0);
     barrier_lds();                          // ... and everyone else's; the oldest image and the oldest record slot are free
     lap(1);
-    if (it + depth + 1 < n_my) fetch_record(it + depth + 1);
-    pending_gathers = (it + depth < n_my && WHATIF != 1) ? issue_gathers(it + depth) : 0;
-    if (depth == 1) pending_gathers = 0;    // they are the gathers the next iteration waits for
+    if constexpr (DEPTH == 1) {             // the next unit's gathers first, then the record of the unit after it
+      if (it + 1 < n_my && WHATIF != 1) issue_gathers(it + 1);
+      if (it + 2 < n_my) fetch_record(it + 2);
+    } else {
+      if (it + depth + 1 < n_my) fetch_record(it + depth + 1);
+      pending_gathers = (it + depth < n_my && WHATIF != 1) ? issue_gathers(it + depth) : 0;
+    }
     lap(2);
     const int32_t* l_rec = reinterpret_cast<const int32_t*>(lds + (it % n_recs) * rec_bytes);
     const unsigned char* image = images + (it % n_images) * image_bytes;
@@ -441,11 +446,10 @@ inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_
   }
   const int64_t units = 2LL * a.n_clusters;
   if (g_cluster_kernel != 2) {
-    // persistent streaming form: depth + 2 record slots + depth + 1 images per workgroup; two workgroups per CU.  Depth 2 (gathers
-    // two units ahead) when that fits into half a CU's LDS, else depth 1
+    // persistent streaming form: depth + 2 record slots + depth + 1 images per workgroup; two workgroups per CU.  Gathers run one
+    // unit ahead; two units ahead (GTS_OPT_CLUSTER_RING = 2, where that fits) is kept for A/B runs: no gain measured
     const int64_t rec_slot = 1024LL * ((a.layout.words + 255) / 256), image = p.slot_bytes - p.image_off;
-    int depth = g_cluster_ring > 0 ? std::min(g_cluster_ring, 4) : (4 * rec_slot + 3 * image <= kMaxLds / 2 ? 2 : 1);
-    while (depth > 1 && (depth + 2) * rec_slot + (depth + 1) * image > kMaxLds) --depth;
+    const int depth = (g_cluster_ring == 2 && WHATIF == 0 && 4 * rec_slot + 3 * image <= kMaxLds) ? 2 : 1;
     const int64_t wg_lds = (depth + 2) * rec_slot + (depth + 1) * image;
     if (wg_lds > kMaxLds || a.layout.words > 512) return GTS_ERR_SHAPE;
     a.ring = depth;
@@ -454,9 +458,16 @@ inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_
     const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g_cluster_per_cu > 0 ? g_cluster_per_cu : 2, kMaxLds / wg_lds)));
     int64_t grid = static_cast<int64_t>(device_cus()) * per_cu;
     grid = std::max<int64_t>(8, std::min(grid, (units + 7) / 8 * 8)) / 8 * 8;
-    static const bool once = (allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF>), true);
+    static const bool once = (allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF, 1>),
+                              allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF == 0 ? 0 : WHATIF, WHATIF == 0 ? 2 : 1>), true);
     (void)once;
-    spmm_cluster_stream_kernel<BWD, ARGB, WHATIF><<<dim3(static_cast<unsigned>(grid)), waves * kWave, wg_lds, st>>>(a);
+    if constexpr (WHATIF == 0) {
+      if (depth == 2) {
+        spmm_cluster_stream_kernel<BWD, ARGB, 0, 2><<<dim3(static_cast<unsigned>(grid)), waves * kWave, wg_lds, st>>>(a);
+        return launch_status();
+      }
+    }
+    spmm_cluster_stream_kernel<BWD, ARGB, WHATIF, 1><<<dim3(static_cast<unsigned>(grid)), waves * kWave, wg_lds, st>>>(a);
     return launch_status();
   }
   // loader / consumer ring: as many slots as fit (at least 2: one loader), at most kMaxRing
