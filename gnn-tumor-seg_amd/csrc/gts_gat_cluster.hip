@@ -229,7 +229,7 @@ struct GatClusterArgs {
   const float* vec;        // forward: bias [H, 256] or null;  backward: attn_l | attn_r [2][H, 256] or null
   float* out;              // forward: out [N, H, 256];  backward: gft
   unsigned table_bytes, side_bytes, vec_bytes;
-  int heads, act;
+  int heads, act, nt;
   int side_floats, chunk_slots, side_pieces;
   int rec_bytes, side_slot_bytes, image_bytes;   // LDS: 3 record slots | 3 side slots | 3 vector slots of 1 KiB | 2 images
   int own_off;             // edge pass: byte offset of the own-row section inside an image
@@ -291,7 +291,10 @@ __device__ __forceinline__ int reduce_wsum_rows(const GatClusterArgs& a, const i
         for (int t = 0; t < 4; ++t) o.v[t] = o.v[t] > 0.0f ? o.v[t] : expm1f(o.v[t]);
       }
     }
-    if (have) o.store(a.out + (static_cast<size_t>(l_rec[a.layout.rows + j]) * a.heads * kF + sub * (kF / 2) + hl * 4));
+    if (have) {   // streamed out (GTS_OPT_CLUSTER_STREAMING, default on): the rows just written do not push the halo slices out of the XCD's L2
+      float* dst = a.out + (static_cast<size_t>(l_rec[a.layout.rows + j]) * a.heads * kF + sub * (kF / 2) + hl * 4);
+      if (a.nt) o.store_nt(dst); else o.store(dst);
+    }
   }
   return trips;
 }
@@ -590,7 +593,7 @@ extern "C" int32_t gts_gat_fwd_cluster_f32(const int32_t* indptr, const int32_t*
   a.table_bytes = static_cast<unsigned>(n * heads * kF * 4);
   a.side_bytes = static_cast<unsigned>(n_clusters * heads * p.side_floats * 4);
   a.vec_bytes = static_cast<unsigned>(heads * kF * 4);
-  a.heads = nh, a.act = activation;
+  a.heads = nh, a.act = activation, a.nt = g_cluster_nt < 0 ? 1 : (g_cluster_nt & 1);
   return launch_gat_cluster<0>(a, p, st);
 }
 
@@ -625,7 +628,7 @@ extern "C" int32_t gts_gat_bwd_src_cluster_f32(const int32_t* t_indptr, const in
   a.table_bytes = static_cast<unsigned>(n * heads * kF * 4);
   a.side_bytes = static_cast<unsigned>(n_clusters * heads * p.side_floats * 4);
   a.vec_bytes = static_cast<unsigned>(2 * heads * kF * 4);
-  a.heads = nh, a.act = 0;
+  a.heads = nh, a.act = 0, a.nt = g_cluster_nt < 0 ? 1 : (g_cluster_nt & 1);
   return launch_gat_cluster<1>(a, p, st);
 }
 

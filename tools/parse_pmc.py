@@ -33,8 +33,9 @@ def short(name):
                        # (both are summed into the label: the bench brackets the whole library call)
                        ("gat_fwd_kernel<4, 64>", "gat_fwd"), ("gat_bwd_edge_kernel<4, 64>", "gat_bwd_edge"),
                        ("gat_bwd_src_kernel<4, 64>", "gat_bwd_src"),
-                       ("gat_cluster_stream_kernel<false", "gat_fwd"), ("gat_weights_one_chunk_kernel<false>", "gat_fwd"),
-                       ("gat_cluster_stream_kernel<true", "gat_bwd_src"), ("gat_weights_one_chunk_kernel<true>", "gat_bwd_src")):
+                       ("gat_cluster_stream_kernel<0,", "gat_fwd"), ("gat_weights_one_chunk_kernel<false>", "gat_fwd"),
+                       ("gat_cluster_stream_kernel<1,", "gat_bwd_src"), ("gat_weights_one_chunk_kernel<true>", "gat_bwd_src"),
+                       ("gat_cluster_stream_kernel<2,", "gat_bwd_edge"), ("gat_edge_finish_kernel", "gat_bwd_edge")):
         if key in name:
             return label
     return None

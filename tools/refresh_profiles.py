@@ -82,9 +82,9 @@ for tag, rows, label in (("", c2, "C2"), ("b8_", b8, "--config c4 (8 graphs per 
         avg[f"{tag}source"] = f"profiles/{rnd}_bench_c2_{tag[:-1]}_kernel_stats.csv ({label})"
 avg["c3_source"] = f"profiles/{rnd}_bench_c3_kernel_stats.csv (--config c3)"
 # hidden-layer launches only (D = 256); the clustered form of a call = its weight pass + the streaming kernel
-for key, plain, clustered in (("gat_fwd", "gat_fwd_kernel<4, 64>", ("gat_cluster_stream_kernel<false", "gat_weights_one_chunk_kernel<false>")),
-                              ("gat_bwd_edge", "gat_bwd_edge_kernel<4, 64>", ()),
-                              ("gat_bwd_src", "gat_bwd_src_kernel<4, 64>", ("gat_cluster_stream_kernel<true", "gat_weights_one_chunk_kernel<true>"))):
+for key, plain, clustered in (("gat_fwd", "gat_fwd_kernel<4, 64>", ("gat_cluster_stream_kernel<0,", "gat_weights_one_chunk_kernel<false>")),
+                              ("gat_bwd_edge", "gat_bwd_edge_kernel<4, 64>", ("gat_cluster_stream_kernel<2,", "gat_edge_finish_kernel")),
+                              ("gat_bwd_src", "gat_bwd_src_kernel<4, 64>", ("gat_cluster_stream_kernel<1,", "gat_weights_one_chunk_kernel<true>"))):
     parts = [(needle, mean_us(c3, (needle,))[0]) for needle in clustered if any(needle in n for n in c3)]
     if parts:
         avg[f"{key}_avg_us"], avg[f"{key}_form"] = round(sum(us for _, us in parts), 2), "clustered"
