@@ -637,3 +637,28 @@ def test_gat_act_backward_in_the_next_layers_gemm_equals_the_pass_of_its_own(n, 
             assert float((got - want).abs().max()) <= 1e-4 * scale + 1e-9, name
         else:
             assert torch.equal(got, want), name
+
+
+def test_gat_act_link_stands_down_when_a_dropout_sits_between_the_layers():
+    """With feat_drop > 0 in training mode a layer's input is no longer the producer's ELU output, so the consumer must not
+    apply ELU' through it: the linked and the unlinked backward must agree (same dropout masks via the same seed)."""
+    from model.networks import GAT
+    n = 6000
+    src, dst = random_coo(n, 5 * n, seed=4, min_in_degree=1)
+    g = gts.Graph(src, dst, n).to(DEV)
+    torch.manual_seed(0)
+    net = GAT(4, [64, 64], 4, [4, 4], [False, False], feat_drop=0.3).to(DEV).train()
+    x = torch.from_numpy(synth.node_features(n, 4, 5)).to(DEV)
+    y = torch.from_numpy(synth.node_labels(n, 5)).to(DEV)
+    grads = []
+    for fold in (True, False):
+        gnn.FOLD_GAT_ACT_BWD = fold
+        try:
+            net.zero_grad(set_to_none=True)
+            torch.manual_seed(7)
+            F.cross_entropy(net(g, x), y).backward()
+        finally:
+            gnn.FOLD_GAT_ACT_BWD = True
+        grads.append([p.grad.clone() for p in net.parameters()])
+    for a, b in zip(*grads):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
