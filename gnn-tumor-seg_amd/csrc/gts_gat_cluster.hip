@@ -286,9 +286,12 @@ __device__ __forceinline__ int reduce_wsum_rows(const GatClusterArgs& a, const i
         const float4 bs = *reinterpret_cast<const float4*>(l_vec + hl * 4);
         o.v[0] += bs.x, o.v[1] += bs.y, o.v[2] += bs.z, o.v[3] += bs.w;
       }
-      if (a.act == 1) {
+      if (a.act == 1) {   // straight-line: four independent expm1f chains, then the selects (same values as the branchy form, NaN included)
+        float e[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) o.v[t] = o.v[t] > 0.0f ? o.v[t] : expm1f(o.v[t]);
+        for (int t = 0; t < 4; ++t) e[t] = expm1f(o.v[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o.v[t] = o.v[t] > 0.0f ? o.v[t] : e[t];
       }
     }
     if (have) {   // streamed out (GTS_OPT_CLUSTER_STREAMING, default on): the rows just written do not push the halo slices out of the XCD's L2
