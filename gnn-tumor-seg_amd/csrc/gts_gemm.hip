@@ -280,7 +280,9 @@ void gemm_kernel(const GemmArgs p) {
   float csum[TM];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) csum[tm] = 0.f;
-  const bool want_colsum = !AKC && p.colsum != nullptr && tile_n == 0 && wn == 0;
+  // the wave that sums the A columns of row block wm: one per SIMD where the wave grid is square (wave w runs on SIMD w % 4,
+  // so `wn == 0` would put the four of them — and their vector adds, which the f32 matrix pipe does not overlap — on SIMD 0)
+  const bool want_colsum = !AKC && p.colsum != nullptr && tile_n == 0 && wn == (WM == WN ? wm : 0);
 
   v4f ra[TA::kVec], rb[TB::kVec];
   auto fetch_a = [&](v4f (&dst)[TA::kVec], int t) {
@@ -320,7 +322,6 @@ void gemm_kernel(const GemmArgs p) {
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][j], bf[tn][j], acc[tm][tn], 0, 0, 0);
     }
   };
-
   Probe::mark(0);
   auto stash = [&](int image) {
     TA::store(ra, lds + image * kImage);
@@ -601,10 +602,19 @@ constexpr unsigned kOutOfRange = 0x7FFFFFF0u;   // byte offset no operand panel 
 
 // TM + TN 16-byte buffer loads: address = panel base (SGPR resource) + lane offset (one VGPR per
 // fragment row block) + reduction offset (SGPR); offsets past the panel's bytes read as 0
-template <int TM, int TN>
+template <int TM, int TN, bool B_FIRST = false>
 __device__ __forceinline__ void load_fragments(v4f (&af)[TM], v4f (&bf)[TN], __amdgpu_buffer_rsrc_t ra,
                                                __amdgpu_buffer_rsrc_t rb, const unsigned (&off_a)[TM],
                                                const unsigned (&off_b)[TN], int k_bytes) {
+  if constexpr (B_FIRST) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+      bf[tn] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rb, off_b[tn], k_bytes, 0));
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+      af[tm] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ra, off_a[tm], k_bytes, 0));
+    return;
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
     af[tm] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ra, off_a[tm], k_bytes, 0));
@@ -648,7 +658,7 @@ struct PanelStage {   // one GEMM of the panel kernel: c[rows of the panel, rb] 
 // most of its code (the generic kernel is ~100 KB of instructions, more than the instruction cache).
 enum : int { kEpiBias = 1, kEpiRelu = 2, kEpiMaskBits = 4, kEpiScores = 8, kEpiBitsOut = 16, kEpiEluSums = 32, kEpiRuntime = 256, kEpiAbsent = -1 };
 
-template <int WM, int WN, int DEPTH, int F = kEpiRuntime, int ROWS = kR240>
+template <int WM, int WN, int DEPTH, int F = kEpiRuntime, int ROWS = kR240, int ILV = 0>
 __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int sched, int m0, int n0, int row_end) {
   constexpr bool G = (F & kEpiRuntime) != 0;
   constexpr int WTM = ROWS / WM, WTN = kC240 / WN, TM = WTM / 16, TN = WTN / 16;
@@ -690,8 +700,8 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
     for (; g + R <= n_full; g += R) {
 #pragma unroll
       for (int u = 0; u < R; ++u) {
-        load_fragments(af[(u + DEPTH) % R], bf[(u + DEPTH) % R], ra, rb, off_a, off_b,
-                       64 * min(g + u + DEPTH, n_full - 1));
+        load_fragments<TM, TN, ILV >= 0>(af[(u + DEPTH) % R], bf[(u + DEPTH) % R], ra, rb, off_a, off_b,
+                                         64 * min(g + u + DEPTH, n_full - 1));
         mfma_group(acc, af[u], bf[u]);
       }
       // pin the software pipeline: the loads of a group are issued before the MFMAs of the group
@@ -699,8 +709,20 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
       // then waits for each load right after issuing it)
 #pragma unroll
       for (int u = 0; u < R; ++u) {
-        __builtin_amdgcn_sched_group_barrier(0x020, TM + TN, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+        if constexpr (ILV < 0) {   // the loads of a group in one burst in front of its MFMAs (rounds 1 - 2; kept for A/B runs)
+          __builtin_amdgcn_sched_group_barrier(0x020, TM + TN, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+        } else {   // one load, then kPer MFMAs, ...: a burst of nine loads holds up the wave's own MFMA issue (round 3)
+          constexpr int kPer = ILV > 0 ? ILV : 4 * TM * TN / (TM + TN);
+          constexpr int kRest = 4 * TM * TN - kPer * (TM + TN);
+          static_assert(kPer >= 1 && kRest >= 0, "MFMAs per load do not fit the group");
+#pragma unroll
+          for (int l = 0; l < TM + TN; ++l) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
+          }
+          if (kRest > 0) __builtin_amdgcn_sched_group_barrier(0x008, kRest, 0);
+        }
       }
     }
 #pragma unroll
@@ -855,7 +877,7 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
   }
 }
 
-template <int WM, int WN, int DEPTH, class Probe = NoProbe, int F1 = kEpiRuntime, int F2 = kEpiRuntime, int ROWS = kR240>
+template <int WM, int WN, int DEPTH, class Probe = NoProbe, int F1 = kEpiRuntime, int F2 = kEpiRuntime, int ROWS = kR240, int ILV = 0>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_kernel(const GemmArgs p) {
   constexpr int WTN = kC240 / WN;
   static_assert((ROWS / WM) % 16 == 0 && WTN % 16 == 0 && WTN % 4 == 0 && (WM * WN) % 4 == 0, "wave tiles are whole 16x16 tiles");
@@ -872,7 +894,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
   s0.ra = p.ra, s0.rb = p.rb, s0.ldc = p.ldc, s0.relu = p.relu, s0.c = p.c, s0.bias = p.bias, s0.mask = p.mask;
   s0.sc_l = p.sc_l, s0.sc_r = p.sc_r, s0.sc_el = p.sc_el, s0.sc_er = p.sc_er;
   s0.bits_out = p.bits_out, s0.bits_in = p.bits_in, s0.mask_kind = p.mask_kind, s0.col_partial = p.col_partial;
-  panel_stage<WM, WN, DEPTH, F1, ROWS>(s0, lds, p.sched, m0, n0, row_end);
+  panel_stage<WM, WN, DEPTH, F1, ROWS, ILV>(s0, lds, p.sched, m0, n0, row_end);
   Probe::mark(2);
   // With c2 set a second GEMM follows in the same launch: the rows this workgroup has just stored are
   // its A operand (the next layer's fc_pool behind fc_self + fc_neigh; the next input gradient behind
@@ -891,7 +913,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
     s1.lda[0] = s1.lda[1] = p.ldc, s1.ldb[0] = s1.ldb[1] = p.ldb2;
     s1.kseg[0] = p.rb, s1.kseg[1] = 0;
     s1.ra = p.ra, s1.rb = p.rb2, s1.ldc = p.ldc2, s1.relu = p.relu2, s1.c = p.c2, s1.bias = p.bias2, s1.mask = nullptr;
-    panel_stage<WM, WN, DEPTH, F2 == kEpiAbsent ? kEpiRuntime : F2, ROWS>(s1, lds, p.sched, m0, 0, row_end);
+    panel_stage<WM, WN, DEPTH, F2 == kEpiAbsent ? kEpiRuntime : F2, ROWS, ILV>(s1, lds, p.sched, m0, 0, row_end);
   }
   Probe::mark(3);
 }
@@ -917,10 +939,22 @@ int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
     const int f2 = p.c2 == nullptr ? kEpiAbsent : (p.bias2 ? kEpiBias : 0) | (p.relu2 ? kEpiRelu : 0);
     constexpr int kFwd = kEpiBias | kEpiRelu;
     if (whole && f1 == (kFwd | kEpiBitsOut) && f2 == kFwd) {          // fc_self + fc_neigh, then the next fc_pool (training)
+      if constexpr (ROWS == kR240) {
+        if (q.sched & 8) {   // A/B: the grouped load order of rounds 1 - 2
+          gemm_panel_direct_kernel<3, 4, 1, NoProbe, kFwd | kEpiBitsOut, kFwd, ROWS, -1><<<grid, 768, 0, st>>>(q);
+          return launch_status();
+        }
+      }
       gemm_panel_direct_kernel<3, 4, 1, NoProbe, kFwd | kEpiBitsOut, kFwd, ROWS><<<grid, 768, 0, st>>>(q);
       return launch_status();
     }
     if (whole && f1 == kEpiMaskBits && f2 == 0) {                     // a layer's input gradient, then g @ W_neigh below
+      if constexpr (ROWS == kR240) {
+        if (q.sched & 8) {   // A/B: the grouped load order of rounds 1 - 2
+          gemm_panel_direct_kernel<3, 4, 1, NoProbe, kEpiMaskBits, 0, ROWS, -1><<<grid, 768, 0, st>>>(q);
+          return launch_status();
+        }
+      }
       gemm_panel_direct_kernel<3, 4, 1, NoProbe, kEpiMaskBits, 0, ROWS><<<grid, 768, 0, st>>>(q);
       return launch_status();
     }

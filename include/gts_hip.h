@@ -423,7 +423,9 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
 #define GTS_OPT_GEMM_SCHED 7  /* K11 scheduling bits (default 1): 1 = s_setprio by progress inside a reduction tile (LDS kernels),
                                 2 = non-temporal stores of the output panel (direct-to-fragment kernels; no gain measured),
                                 4 = the direct-to-fragment kernels keep every epilogue switch a run-time argument (the generic
-                                    instantiation) instead of the compile-time epilogues of the layer-stack launches (A/B runs) */
+                                    instantiation) instead of the compile-time epilogues of the layer-stack launches (A/B runs),
+                                8 = the chained 240-row launches of the layer stack issue the nine fragment loads of a reduction
+                                    group in one burst (rounds 1 - 2) instead of one load per eight MFMAs (A/B runs; same bits) */
 #define GTS_OPT_CLUSTER_STREAMING 8 /* clustered K1 / K2: bit 0 = non-temporal stores of out / gx; -1 = per-kernel default */
 #define GTS_OPT_GAT_WALK 14          /* K5-K8: 1 = walk the (node, head) rows head-major (default), 0 = node-major */
 #define GTS_OPT_GAT_CLUSTER_WAVES 15 /* clustered GAT aggregation: waves per persistent workgroup (0 = default 12; up to 16) */
