@@ -54,6 +54,7 @@ struct GemmArgs {
   const float* pa[kMaxProblems];  // per-problem operands (same shapes)
   const float* pb[kMaxProblems];
   float* colsum;        // [problem][split][ra] column sums of A, or null
+  unsigned colsum_mask; // bit q: problem q wants its column sums (wgrad_stream_kernel; the other kernels sum them all)
   int n_problems;       // 0 -> plain GEMM
   int tiles_n;          // output tiles along rb per problem
   int n_splits;
@@ -1250,6 +1251,192 @@ __global__ __launch_bounds__(1024, 4) void wgrad_dma_kernel(const GemmArgs p) {
 // out_q[i] = sum_s slab[q][s][i] for problems q, summed in split order inside four interleaved
 // split groups whose partials are then added in group order: a fixed association, so results
 // are bitwise reproducible.  One float4 column per thread-quad.
+// ---- weight gradients, a main loop of MFMAs, LDS reads and nothing else (round 3) -----------------------------------
+// The f32 MFMA and the vector ALU share their arithmetic on gfx950: a vector instruction between two MFMAs costs the
+// wave ~17 cycles of matrix-pipe time, each further one ~4 (profiles/r03_mfma_valu_coissue.log).  The two kernels above
+// carry 20 - 30 of them per reduction tile (fragment addresses, DMA offsets, the bias column sums in every wave): that,
+// not the issue of the LDS reads, is what held them at 87.9 % of the matrix pipe.  Same 256 x 256 tile, slabs, MFMA
+// order and column-sum order as gemm_kernel<256, 256, 4, 4, false, false, true> (bit-identical results), same
+// LDS-DMA tile copies as wgrad_dma_kernel, but:
+//   * LDS holds [A image 0 | A image 1 | B image 0 | B image 1] (32 KiB each), so ONE address register per 32-row
+//     block reaches every fragment element of BOTH images through the immediate offsets of ds_read2st64_b32 (units of
+//     256 B: reduction row r of image I sits 4 r + 128 I units up; a read fetches steps j, j + 1);
+//   * the reduction tiles are walked two at a time, the image a compile-time fact;
+//   * a tile's DMA descriptor is built by the scalar unit (base and length of the tile's 32 rows: rows past the split
+//     read as zeros), the lane offsets never change;
+//   * the bias column sums run in one wave per SIMD (wn == wm) and only for the problems that have a bias, in a
+//     copy of the loop of their own, so the other waves' loop has no vector instruction at all.
+// Fragment reads are issued one pair of steps ahead by inline assembly (the compiler would pair tm = 0 / 1 into
+// ds_read2_b32 and add up a new address per step); each wait carries the fragment registers as operands so the MFMAs
+// that consume them cannot be scheduled above it.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int O0, int O1>
+__device__ __forceinline__ v2f lds_read2st64(unsigned addr) {
+  static_assert(O0 >= 0 && O1 <= 255, "ds_read2st64_b32 offsets are 8 bits");
+  v2f r;
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(addr), "n"(O0), "n"(O1));
+  return r;
+}
+
+template <class Probe = NoProbe>
+__global__ __launch_bounds__(1024, 4) void wgrad_stream_kernel(const GemmArgs p) {
+  constexpr int BM = 256, BN = 256, WM = 4, WN = 4, WTM = 64, WTN = 64, TM = 2, TN = 2;
+  constexpr int kPlane = kBK * BM;   // floats of one operand image (32 KiB)
+  static_assert(BM == BN && kPlane * 4 == 128 * 256, "image I of an operand sits 128 offset units above image 0");
+  __shared__ float lds[4 * kPlane];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int i = lane & 31, h = lane >> 5;
+  const int problem = blockIdx.y / p.tiles_n, tile_n = blockIdx.y % p.tiles_n;
+  const int m0 = blockIdx.x * BM, n0 = tile_n * BN;   // output rows (columns of g) / output columns (columns of act)
+  const float* g = kernarg_entry<const float*>(offsetof(GemmArgs, pa), problem);
+  const float* act = kernarg_entry<const float*>(offsetof(GemmArgs, pb), problem);
+  const int ldg = p.lda[0], lda = p.ldb[0];
+  const int n_tiles_all = (p.kseg[0] + kBK - 1) / kBK;
+  const int t_beg = min(n_tiles_all, static_cast<int>(blockIdx.z) * p.tiles_per_split);
+  const int t_end = min(n_tiles_all, t_beg + p.tiles_per_split);
+  const int row_beg = t_beg * kBK, rows = min(p.kseg[0], t_end * kBK) - row_beg;   // reduction rows of this split
+  const int n_tiles = t_end - t_beg;
+  // wave w copies rows w and w + 16 of both tiles; a lane whose four columns lie past the operand is parked outside
+  // the descriptor (zeros land in LDS)
+  const bool g_ok = m0 + 4 * lane < p.ra, a_ok = n0 + 4 * lane < p.rb;
+  const unsigned vg0 = g_ok ? static_cast<unsigned>(wave * ldg + m0 + 4 * lane) * 4 : kOutOfRange;
+  const unsigned vg1 = g_ok ? static_cast<unsigned>((wave + 16) * ldg + m0 + 4 * lane) * 4 : kOutOfRange;
+  const unsigned va0 = a_ok ? static_cast<unsigned>(wave * lda + n0 + 4 * lane) * 4 : kOutOfRange;
+  const unsigned va1 = a_ok ? static_cast<unsigned>((wave + 16) * lda + n0 + 4 * lane) * 4 : kOutOfRange;
+  auto dma = [&](int t, int image) __attribute__((always_inline)) {   // tile t (counted from t_beg) -> image
+    const int r0 = row_beg + t * kBK, nr = min(kBK, rows - t * kBK);
+    __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g + static_cast<size_t>(r0) * ldg), 0,
+                                                                  nr * ldg * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t ract = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(act + static_cast<size_t>(r0) * lda), 0,
+                                                                    nr * lda * 4, 0x00020000);
+    float* ia = lds + image * kPlane + wave * BM;
+    float* ib = lds + (2 + image) * kPlane + wave * BN;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, ia, 16, vg0, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, ia + 16 * BM, 16, vg1, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ract, ib, 16, va0, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ract, ib + 16 * BN, 16, va1, 0, 0, 0);
+  };
+
+  v16f acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+  float csum[TM] = {0.f, 0.f};
+  const bool want_colsum = p.colsum != nullptr && tile_n == 0 && wn == wm && ((p.colsum_mask >> problem) & 1u) != 0;
+
+  // fragment addresses (LDS bytes) of image 0: element (reduction row 4 h, column of this lane's 32-row block)
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)lds));
+  const unsigned a_addr0 = lds0 + static_cast<unsigned>(4 * h * BM + wm * WTM + i) * 4, a_addr1 = a_addr0 + 128;
+  const unsigned b_addr0 = lds0 + static_cast<unsigned>(2 * kPlane + 4 * h * BN + wn * WTN + i) * 4, b_addr1 = b_addr0 + 128;
+  v2f fa[2][TM], fb[2][TN];   // two pairs of steps in flight: pair q in slot q & 1
+  fa[0][0] = fa[0][1] = fa[1][0] = fa[1][1] = v2f{0.f, 0.f};
+  fb[0][0] = fb[0][1] = fb[1][0] = fb[1][1] = v2f{0.f, 0.f};
+
+  // the four reads of pair Q (steps 2 Q, 2 Q + 1: reduction rows 8 (Q / 2) + 2 (Q % 2) + {0, 1} (+ 4 h)) of image IMG
+  auto issue = [&](auto img_c, auto pair_c) __attribute__((always_inline)) {
+    constexpr int IMG = decltype(img_c)::value, Q = decltype(pair_c)::value;
+    constexpr int O = 4 * (8 * (Q / 2) + 2 * (Q % 2)) + 128 * IMG;
+    fa[Q & 1][0] = lds_read2st64<O, O + 4>(a_addr0);
+    fa[Q & 1][1] = lds_read2st64<O, O + 4>(a_addr1);
+    fb[Q & 1][0] = lds_read2st64<O, O + 4>(b_addr0);
+    fb[Q & 1][1] = lds_read2st64<O, O + 4>(b_addr1);
+  };
+  auto multiply = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][tm][e], fb[slot][tn][e], acc[tm][tn], 0, 0, 0);
+  };
+  float half_sum[TM] = {0.f, 0.f};
+  // one reduction tile out of image IMG; on entry the reads of its pair 0 are in flight (slot 0)
+  auto tile = [&](auto img_c, auto cs_c, int t) __attribute__((always_inline)) {
+    constexpr int IMG = decltype(img_c)::value;
+    constexpr bool CS = decltype(cs_c)::value;
+    auto pair = [&](auto pair_c) __attribute__((always_inline)) {
+      constexpr int Q = decltype(pair_c)::value, S = Q & 1;
+      if constexpr (Q < 7) {
+        issue(img_c, std::integral_constant<int, Q + 1>{});
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[S][0]), "+v"(fa[S][1]), "+v"(fb[S][0]), "+v"(fb[S][1]));
+      } else {
+        // every read of this image has been issued: wait for them and for this wave's pieces of the next tile, meet
+        // the other waves, hand the image to the DMA of the tile after next and start on the next image
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"
+                     : "+v"(fa[S][0]), "+v"(fa[S][1]), "+v"(fb[S][0]), "+v"(fb[S][1]) : : "memory");
+        if (t + 2 < n_tiles) dma(t + 2, IMG);
+        if (t + 1 < n_tiles) issue(std::integral_constant<int, IMG ^ 1>{}, std::integral_constant<int, 0>{});
+      }
+      if constexpr (Q % 2 == 0) {   // waves further into a tile yield MFMA issue (the builtin wants a literal)
+        if constexpr (Q == 0) __builtin_amdgcn_s_setprio(3);
+        else if constexpr (Q == 2) __builtin_amdgcn_s_setprio(2);
+        else if constexpr (Q == 4) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+      if constexpr (CS) {   // csum += (a0 + a1) + (a2 + a3) per group of four steps, as gemm_kernel sums them; the adds are
+                            // pinned here (left to the compiler they drift away from the fragments, which it then spills)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          if constexpr (Q % 2 == 0) {
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(half_sum[tm]) : "v"(fa[S][tm][0]), "v"(fa[S][tm][1]));
+          } else {
+            float upper;
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(upper) : "v"(fa[S][tm][0]), "v"(fa[S][tm][1]));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(upper) : "v"(half_sum[tm]), "v"(upper));
+            asm volatile("v_add_f32 %0, %1, %2" : "+v"(csum[tm]) : "v"(csum[tm]), "v"(upper));
+          }
+        }
+      }
+      multiply(S);
+    };
+    pair(std::integral_constant<int, 0>{}), pair(std::integral_constant<int, 1>{}), pair(std::integral_constant<int, 2>{}),
+        pair(std::integral_constant<int, 3>{}), pair(std::integral_constant<int, 4>{}), pair(std::integral_constant<int, 5>{}),
+        pair(std::integral_constant<int, 6>{}), pair(std::integral_constant<int, 7>{});
+  };
+  auto reduce = [&](auto cs_c) __attribute__((always_inline)) {
+    int t = 0;
+    for (; t + 1 < n_tiles; t += 2) {
+      tile(std::integral_constant<int, 0>{}, cs_c, t);
+      tile(std::integral_constant<int, 1>{}, cs_c, t + 1);
+    }
+    if (t < n_tiles) tile(std::integral_constant<int, 0>{}, cs_c, t);
+  };
+
+  Probe::mark(0);
+  if (n_tiles > 0) {
+    dma(0, 0);
+    if (n_tiles > 1) {
+      dma(1, 1);
+      asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // the four pieces of tile 0 have landed, everybody's
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  }
+  Probe::mark(1);
+  if (want_colsum) reduce(std::true_type{});
+  else reduce(std::false_type{});
+  __builtin_amdgcn_s_setprio(0);
+  Probe::mark(2);
+  const size_t slab = static_cast<size_t>(problem) * p.n_splits + blockIdx.z;
+  write_tile<BM, BN, WM, WN>(p, lds, p.c + slab * p.ra * p.ldc, acc, m0, n0);
+  Probe::mark(3);
+  if (want_colsum) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const float total = csum[tm] + __shfl_xor(csum[tm], 32, kWave);   // the two kk halves
+      const int row = m0 + wm * WTM + tm * 32 + i;
+      if (h == 0 && row < p.ra) p.colsum[slab * p.ra + row] = total;
+    }
+  }
+}
+
 struct ReduceArgs {   // weight-slab + bias-slab jobs of every problem in one launch (blockIdx.y = job)
   const float* slabs[2 * kMaxProblems];
   float* out[2 * kMaxProblems];
@@ -1690,7 +1877,7 @@ inline void wgrad_candidate(int variant, int64_t k, int* bm, int* bn, int64_t* s
   *bm = 128, *bn = k <= 64 ? 64 : 128, *slots = 512;   // 2 workgroups per CU
   if (k <= 64) return;
   if (variant == 2) *bn = 256;
-  if (variant == 4 || variant == 5 || variant == 7 || variant == 8 || variant == 9) *bm = 256, *bn = 256, *slots = 256;  // one workgroup per CU
+  if (variant == 4 || variant == 5 || variant == 6 || variant == 7 || variant == 8 || variant == 9) *bm = 256, *bn = 256, *slots = 256;  // one workgroup per CU
 }
 
 inline WgradPlan wgrad_plan(int64_t m, int64_t n, int64_t k, int n_problems) {
@@ -1704,8 +1891,10 @@ inline WgradPlan wgrad_plan(int64_t m, int64_t n, int64_t k, int n_problems) {
   // Few problems with LARGE outputs (GAT: one or two 1024 x 1024 gradients per layer, 16 output
   // tiles of 256 x 256 x 16 splits = 256 workgroups): the double-buffered 256x256 tile again
   // (C3 308 -> 312 graphs/s, profiles/r02_ab_c3_wgrad.log).
-  static const int kMany[2] = {4, 2};
-  static const int kFewLarge[2] = {4, 1};
+  // Round 3: 6 (wgrad_stream_kernel: the same tile and bits as 4 with a main loop free of vector instructions) takes
+  // the place of 4 — 1 094 against 1 193 us for the 19 problems of C2 (profiles/r03_tune_wgrad.log).
+  static const int kMany[2] = {6, 2};
+  static const int kFewLarge[2] = {6, 1};
   const bool few = n_problems <= 4;
   const bool large = n * k * n_problems >= (1 << 20);
   const int n_candidates = g_wgrad_variant >= 0 || (few && !large) ? 1 : 2;
@@ -1736,6 +1925,13 @@ int launch_wgrad(const GemmArgs& p, const WgradPlan& plan, hipStream_t st) {
     case 4: return launch_tiles<256, 256, 4, 4, false, false, true>(p, np, splits, st);
     case 8: return launch_tiles<256, 256, 2, 4, false, false, true>(p, np, splits, st);   // 8 waves of 128 x 64: 0.375 LDS reads per MFMA
     case 9: return launch_tiles<256, 256, 4, 2, false, false, true>(p, np, splits, st);   // 8 waves of 64 x 128
+    case 6: {
+      GemmArgs q = p;
+      q.tiles_n = (p.rb + 255) / 256;
+      dim3 grid((p.ra + 255) / 256, q.tiles_n * np, splits);
+      wgrad_stream_kernel<><<<grid, 1024, 0, st>>>(q);
+      return launch_status();
+    }
     case 7: {
       GemmArgs q = p;
       q.tiles_n = (p.rb + 255) / 256;
@@ -2080,6 +2276,8 @@ extern "C" int32_t gts_linear_bwd_weight_f32(const float* const* g, const float*
   p.ra = static_cast<int>(n), p.rb = static_cast<int>(k);
   p.c = workspace, p.ldc = static_cast<int>(k);
   p.colsum = any_bias ? workspace + static_cast<size_t>(n_problems) * splits * n * k : nullptr;
+  for (int q = 0; q < n_problems && any_bias; ++q)
+    if (gb[q]) p.colsum_mask |= 1u << q;
   p.n_problems = n_problems, p.n_splits = splits;
   p.tiles_per_split = (tiles + splits - 1) / splits;
   int rc = launch_wgrad(p, plan, st);

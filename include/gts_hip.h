@@ -414,7 +414,10 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
  * tools/tune_gemm.py).  Returns GTS_ERR_ARGKIND for an unknown option. */
 #define GTS_OPT_GEMM_TILE 1  /* forward tile: -1 automatic, -2 automatic among the 32x32x2 tiles only (a row's result then does
                                 not depend on how many rows the call has: batched == per-sample, bit for bit), 1 = 128x256, 3 = 64x256, 5 = 256x128, 8 = 256x256 double-buffered, 9 = 240-row panels (16x16x4 MFMA) staged through LDS, 10 = the same panels with direct-to-fragment buffer loads (12 waves), 11 / 12 = 4 waves of 240x64, prefetch depth 1 / 2 */
-#define GTS_OPT_WGRAD_TILE 2 /* weight-gradient tile: -1 automatic, 1 = 128x128, 2 = 128x256, 4 = 256x256 double-buffered, 5 = 256x256 direct-to-fragment (no LDS), 7 = 256x256 with the operand tiles moved by LDS-DMA (buffer_load ... lds) */
+#define GTS_OPT_WGRAD_TILE 2 /* weight-gradient tile: -1 automatic, 1 = 128x128, 2 = 128x256, 4 = 256x256 double-buffered, 5 = 256x256 direct-to-fragment (no LDS), 7 = 256x256 with the operand tiles moved by LDS-DMA (buffer_load ... lds),
+                                6 = 7 with a main loop of MFMAs and LDS reads only (immediate-offset fragment reads, scalar-built DMA
+                                    descriptors, bias sums in one wave per SIMD): the automatic choice where 4 was (same bits as 4),
+                                8 / 9 = 256x256 with eight waves of 128x64 / 64x128 */
 #define GTS_OPT_IGRAD_TILE 3 /* input-gradient tile: same numbering as the forward one (default 1) */
 #define GTS_OPT_PROJECT_STREAMING 6  /* K12: non-temporal stores of the projected rows (default 1) */
 #define GTS_OPT_SPMM_ROWS_PER_WAVE 4 /* K1-K4: rows one wave walks (0 = automatic) */

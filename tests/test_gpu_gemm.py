@@ -259,11 +259,12 @@ def test_input_gradient_from_transposed_weights(m, k, n0, n1, mask):
 
 @pytest.mark.parametrize("m,k,n,count", [(60000, 256, 256, 19), (3000, 256, 256, 3), (777, 132, 128, 5), (2049, 64, 128, 2),
                                          (515, 260, 256, 1), (37, 16, 12, 1), (4641, 256, 260, 4), (6, 32, 32, 1)])
-@pytest.mark.parametrize("variant", [5, 7])
+@pytest.mark.parametrize("variant", [5, 7, 6])
 def test_direct_fragment_weight_gradient_against_fp64(hip_lib, m, k, n, count, variant):
     """The alternative 256 x 256 weight-gradient kernels (GTS_OPT_WGRAD_TILE = 5: interleaved 16-row tiles fed by
     16-byte column loads, no LDS; 7: operand tiles moved by LDS-DMA, `buffer_load ... lds`) forced
-    on ragged node counts / widths / split boundaries, several problems per launch, bias sums."""
+    on ragged node counts / widths / split boundaries, several problems per launch, bias sums.  6: the streaming form
+    of 7 whose main loop holds MFMAs and LDS reads only (wgrad_stream_kernel)."""
     gs = [_rand(m, n, seed=500 + q) for q in range(count)]
     acts = [_rand(m, k, seed=600 + q) for q in range(count)]
     dev = [(g.to(DEV), a.to(DEV), q % 2 == 0) for q, (g, a) in enumerate(zip(gs, acts))]
@@ -279,6 +280,36 @@ def test_direct_fragment_weight_gradient_against_fp64(hip_lib, m, k, n, count, v
         if gb is not None:
             _check(gb, g.double().sum(0), g.double().abs().sum(0))
         assert torch.equal(gw, again[q][0])
+
+
+@pytest.mark.parametrize("m,k,n,count", [(60000, 256, 256, 19), (120000, 256, 256, 19), (3000, 256, 256, 3), (777, 132, 128, 5),
+                                         (2049, 64, 128, 2), (515, 260, 256, 1), (37, 16, 12, 1), (4641, 256, 260, 4),
+                                         (6, 32, 32, 1), (33, 256, 256, 2), (64, 256, 256, 1), (96, 256, 256, 32),
+                                         (15000, 1024, 1024, 2)])
+def test_streaming_weight_gradient_equals_the_lds_tile_bit_for_bit(hip_lib, m, k, n, count):
+    """GTS_OPT_WGRAD_TILE = 6 (wgrad_stream_kernel: fragment reads at immediate offsets, scalar-built DMA descriptors, bias
+    sums in one wave per SIMD and only where asked for) walks the same tiles, slabs, MFMA steps and column-sum order as
+    variant 4 (the double-buffered LDS tile): weight and bias gradients agree in every bit — one, two, three and many
+    reduction tiles per split (both image parities and the odd tail), ragged node counts and widths, 32 problems."""
+    gs = [_rand(m, n, seed=700 + q) for q in range(min(count, 4))]
+    acts = [_rand(m, k, seed=800 + q) for q in range(min(count, 4))]
+    dev_g, dev_a = [g.to(DEV) for g in gs], [a.to(DEV) for a in acts]
+    dev = [(dev_g[q % len(gs)], dev_a[(q // 2) % len(acts)], q % 3 != 2) for q in range(count)]
+    got = {}
+    try:
+        for variant in (4, 6):
+            assert hip_lib.gts_set_option(2, variant) == 0
+            got[variant] = dense.linear_bwd_weight_multi(dev)
+    finally:
+        hip_lib.gts_set_option(2, -1)
+    for q, ((gw4, gb4), (gw6, gb6)) in enumerate(zip(got[4], got[6])):
+        assert torch.equal(gw4, gw6), q
+        assert (gb4 is None) == (gb6 is None) == (q % 3 == 2)
+        if gb4 is not None:
+            assert torch.equal(gb4, gb6), q
+    g, a = gs[0], acts[0]
+    _check(got[6][0][0], g.double().t() @ a.double(), g.double().abs().t() @ a.double().abs())
+    _check(got[6][0][1], g.double().sum(0), g.double().abs().sum(0))
 
 
 @pytest.mark.parametrize("m,k0,k1,n,n2", [(60000, 256, 256, 256, 256), (60000, 4, 4, 256, 256), (49999, 132, 0, 256, 64),
