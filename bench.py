@@ -466,7 +466,7 @@ def main():
                 "bound": "mfma",
                 "kernel": "K11, every forward / input-gradient / weight-gradient launch of the step: "
                           "gts::gemm_panel_direct_kernel (16x16x4 MFMA row panels: the chained layer GEMMs, ~58 % of a C2 step) "
-                          "and gts::gemm_kernel<256,256,...> (32x32x2 MFMA split-reduction weight gradients, ~26 %)",
+                          "and gts::wgrad_stream_kernel (32x32x2 MFMA split-reduction weight gradients, ~25 %)",
                 "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                 "flops_per_step": flops / args.steps, "gemm_ms_per_step": round(1e3 * secs / args.steps, 4),

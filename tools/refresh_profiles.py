@@ -73,7 +73,8 @@ panel, panel_calls = mean_us(c2, ("gemm_panel_direct_kernel<3, 4, 1",))
 avg = {"source": f"profiles/{rnd}_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 5 --blocks 2 "
                  "--no-cpu-baseline`, kernel-only durations)",
        "gemm_panel_direct_avg_us": panel, "gemm_panel_direct_calls": panel_calls,
-       "gemm_wgrad_256x256_avg_us": mean_us(c2, ("gemm_kernel<256, 256, 4, 4, false, false, true",))[0]}
+       "gemm_wgrad_256x256_avg_us": mean_us(c2, ("wgrad_stream_kernel",) if any("wgrad_stream_kernel" in n for n in c2)
+                                             else ("gemm_kernel<256, 256, 4, 4, false, false, true",))[0]}
 for tag, rows, label in (("", c2, "C2"), ("b8_", b8, "--config c4 (8 graphs per GPU)"), ("b32_", b32, "--graphs-per-gpu 32")):
     for key, needles in (("spmm_max_fwd_f256", K1), ("spmm_max_bwd_f256", K2)):
         us, calls, form = first_mean(rows, needles)
