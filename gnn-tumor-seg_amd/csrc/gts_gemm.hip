@@ -1411,12 +1411,10 @@ __global__ __launch_bounds__(1024, 4) void wgrad_stream_kernel(const GemmArgs p)
   Probe::mark(0);
   if (n_tiles > 0) {
     dma(0, 0);
-    if (n_tiles > 1) {
-      dma(1, 1);
-      asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // the four pieces of tile 0 have landed, everybody's
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    }
+    if (n_tiles > 1) dma(1, 1);
+    // every piece has landed, everybody's.  vmcnt(0), not (4): should the compiler ever spill around here, its scratch
+    // stores would count in vmcnt too and need not retire in order with the loads
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
   }
   Probe::mark(1);
