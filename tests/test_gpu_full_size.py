@@ -166,7 +166,9 @@ def test_c2_full_size_forward_loss_and_gradients_match_oracle():
 def test_c2_backward_is_the_same_with_bit_masks_float_masks_and_generic_epilogues(hip_lib):
     """The switches of the 256-wide layer launches change where the ReLU masks come from (bits recorded by the
     forward GEMM vs the floats of the saved activation) and which instantiation runs (compile-time vs run-time
-    epilogue), never a sum: loss and every gradient are bitwise the same."""
+    epilogue), when a wave asks for its operand fragments (one load per eight MFMAs vs nine in a burst) and which
+    kernel walks the weight-gradient tiles (wgrad_stream_kernel vs the LDS tile), never a sum: loss and every gradient
+    are bitwise the same."""
     from gts import nn as gnn
 
     hp = HP(4, 4, [256] * 7, None, None)
@@ -189,10 +191,16 @@ def test_c2_backward_is_the_same_with_bit_masks_float_masks_and_generic_epilogue
         gnn.RELU_MASK_BITS = True
         assert hip_lib.gts_set_option(7, 5) == 0          # GTS_OPT_GEMM_SCHED bit 4: generic epilogues
         generic = run()
+        assert hip_lib.gts_set_option(7, 9) == 0          # bit 8: the fragment loads of a reduction group in one burst (rounds 1 - 2)
+        burst = run()
+        assert hip_lib.gts_set_option(7, 1) == 0
+        assert hip_lib.gts_set_option(2, 4) == 0          # GTS_OPT_WGRAD_TILE 4: the LDS tile wgrad_stream_kernel (6, automatic) replaced
+        lds_tile = run()
     finally:
         gnn.RELU_MASK_BITS = True
         hip_lib.gts_set_option(7, 1)
-    for other in (floats, generic):
+        hip_lib.gts_set_option(2, -1)
+    for other in (floats, generic, burst, lds_tile):
         assert other[0] == base[0]
         for a, b in zip(base[1], other[1]):
             assert torch.equal(a, b)
