@@ -17,7 +17,9 @@ so = "/tmp/libgts_probe.so"
 subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off",
                        f"-I{REPO}/include", f"-I{REPO}/gnn-tumor-seg_amd/csrc", "-o", so,
                        os.path.join(REPO, "tools/diag/gemm_probe.hip"),
-                       os.path.join(REPO, "gnn-tumor-seg_amd/csrc/gts_project.hip")])
+                       os.path.join(REPO, "gnn-tumor-seg_amd/csrc/gts_project.hip"),
+                           os.path.join(REPO, "gnn-tumor-seg_amd/csrc/gts_gat.hip"),
+                           os.path.join(REPO, "gnn-tumor-seg_amd/csrc/gts_gat_reduce.hip")])
 lib = ctypes.CDLL(so)
 p, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
 lib.gts_probe_linear_fwd.argtypes = [p, p, p, p, p, p, i64, i64, i64, i64, i32, i32, i32, p]
