@@ -44,6 +44,7 @@ class PinnedRing:
         self.slabs = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(slabs)]
         self.events = [None] * slabs
         self.cur, self.at = 0, 0
+        self.wanted = 0       # bytes the batches so far would have needed in one slab (uploads that did not fit included)
 
     def next_batch(self):
         self.events[self.cur] = torch.cuda.Event()
@@ -51,6 +52,11 @@ class PinnedRing:
         self.cur, self.at = (self.cur + 1) % len(self.slabs), 0
         if self.events[self.cur] is not None:
             self.events[self.cur].synchronize()
+        if self.wanted > self.slabs[self.cur].numel():
+            # a batch outgrew the slabs (a C2 batch: 7.4 MB of features, labels and CSR, then 1.9 MB of schedule records):
+            # its tail went up as plain pageable copies, which block the loader thread for milliseconds.  Grow this slab
+            # once, with room to spare (the slab is idle here: its last copies have completed).
+            self.slabs[self.cur] = torch.empty(self.wanted + self.wanted // 2, dtype=torch.uint8, pin_memory=True)
 
     def upload(self, host, device):
         nbytes = host.numel() * host.element_size()
@@ -59,13 +65,16 @@ class PinnedRing:
             if self.at == 0:      # larger than a whole slab: grow this one (rare; the old block is freed by torch when idle)
                 self.slabs[self.cur] = torch.empty(max(2 * nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
                 start = 0
-            else:                 # slab full: plain copy for the rest of this batch
+            else:                 # slab full: plain copy for the rest of this batch (next_batch() grows the slabs)
+                self.at = start + nbytes
+                self.wanted = max(self.wanted, self.at)
                 return host.to(device)
         stage = self.slabs[self.cur][start:start + nbytes].view(host.dtype).view(host.shape)
         # a plain memcpy: torch's copy_ would start an OpenMP team in the loader thread (a new team per thread, spinning
         # beside the main thread: 47 ms per batch measured), numpy copies in the calling thread
         np.copyto(stage.numpy(), host.numpy())
         self.at = start + nbytes
+        self.wanted = max(self.wanted, self.at)
         return stage.to(device, non_blocking=True)
 
 

@@ -19,6 +19,9 @@ Differences that do not change results:
     share of each global batch and gradients are combined by gts.dist.FlatGradSync (exact
     weighted-CE normalisation); world_size == 1 follows the reference's arithmetic exactly.
 """
+import os
+import sys
+
 import numpy as np
 import torch
 from torch.utils.data import DataLoader
@@ -196,6 +199,10 @@ class GNN:
         copy_stream = torch.cuda.Stream(device=self.device)
         device_index = self.device.index
 
+        import time
+        trace = [] if os.environ.get("GTS_PREFETCH_TRACE") else None     # diagnostic: seconds per stage of the loader thread
+        t_prev = [time.perf_counter()]
+
         def produce():
             try:
                 torch.cuda.set_device(device_index)
@@ -209,15 +216,23 @@ class GNN:
                         slots.put((None, None))
                         continue
                     _ids, graph, feats, labels = item
+                    t0 = time.perf_counter()
                     with torch.cuda.stream(copy_stream):
                         batch = self._to_device(graph, feats, labels)
+                        t1 = time.perf_counter()
                         batch[0].dev()                     # CSR upload belongs to the copy as well
+                        t2 = time.perf_counter()
                         for which in self._schedules_wanted(batch[0].n):
                             batch[0].dev_schedule(which)   # ... and so do the cluster row schedules the step will read
+                        t3 = time.perf_counter()
                         ready = torch.cuda.Event()
                         ready.record(copy_stream)
                         self._pinned_ring.next_batch()
+                        t4 = time.perf_counter()
                     slots.put((batch, ready))
+                    if trace is not None:
+                        trace.append((t0 - t_prev[0], t1 - t0, t2 - t1, t3 - t2, t4 - t3, time.perf_counter() - t4))
+                        t_prev[0] = time.perf_counter()
                 slots.put(None)
             except BaseException as exc:                   # noqa: BLE001 - re-raised in the consumer
                 slots.put(exc)
@@ -242,6 +257,10 @@ class GNN:
                 labels.record_stream(main)
                 yield graph, feats, labels
         finally:
+            if trace:
+                mean = [1e3 * sum(col) / len(trace) for col in zip(*trace)]
+                print("[gts prefetch] ms per batch: loader %.2f | features+labels %.2f | csr %.2f | schedules %.2f | event+ring %.2f | "
+                      "queue %.2f  (%d batches)" % (*mean, len(trace)), file=sys.stderr, flush=True)
             stop.set()
             while worker.is_alive():                       # unblock a producer waiting on a full queue
                 try:
