@@ -567,6 +567,25 @@ def test_prefetched_epochs_equal_plain_epochs_and_errors_surface():
     assert np.isfinite(model.run_epoch())
 
 
+def test_pinned_ring_grows_a_slab_a_batch_has_outgrown_and_keeps_the_bytes():
+    """gts.graph.PinnedRing: uploads that do not fit the current page-locked slab go up as plain copies (same bytes on the
+    device) and make next_batch() grow the slabs, after which a batch of that size is staged entirely through them."""
+    from gts.graph import PinnedRing
+
+    ring = PinnedRing(slabs=2, nbytes=1 << 16)
+    rng = np.random.default_rng(3)
+    parts = [torch.from_numpy(rng.integers(0, 1 << 30, size=n, dtype=np.int32)) for n in (9000, 6000, 5000)]   # 80 000 bytes > 64 KiB
+    for _ in range(5):
+        up = [ring.upload(t, torch.device(DEV)) for t in parts]
+        assert all(torch.equal(d.cpu(), h) for d, h in zip(up, parts))
+        ring.next_batch()
+    assert all(slab.numel() >= 80000 for slab in ring.slabs)
+    assert ring.at == 0
+    up = [ring.upload(t, torch.device(DEV)) for t in parts]
+    assert ring.at >= 80000 and ring.at <= ring.slabs[ring.cur].numel()      # the whole batch sits in the slab now
+    assert all(torch.equal(d.cpu(), h) for d, h in zip(up, parts))
+
+
 def test_row_count_invariant_batched_forward_is_bitwise_the_per_sample_forward():
     """What GNN.evaluate relies on: under dense.row_count_invariant() a block-diagonal batch tall enough
     to select the 240-row panels otherwise (8 x 7 000 nodes) gives every sample the logits of its own
