@@ -312,6 +312,23 @@ def test_streaming_weight_gradient_equals_the_lds_tile_bit_for_bit(hip_lib, m, k
     _check(got[6][0][1], g.double().sum(0), g.double().abs().sum(0))
 
 
+@pytest.mark.parametrize("m,count", [(60000, 19), (15013, 7)])
+def test_streaming_weight_gradient_is_the_same_launch_after_launch(m, count):
+    """wgrad_stream_kernel orders its LDS-DMA tile copies, its hand-placed LDS reads and the image hand-over with explicit
+    wait counts and one barrier per tile: 150 launches on the same operands (full size; a ragged node count with an odd
+    number of reduction tiles per split) must give the bits of the first — a missed wait would show as a stray difference."""
+    gs = [_rand(m, 256, seed=900 + q).to(DEV) for q in range(3)]
+    acts = [_rand(m, 256, seed=950 + q).to(DEV) for q in range(3)]
+    problems = [(gs[q % 3], acts[(q + 1) % 3], q % 2 == 0) for q in range(count)]
+    first = dense.linear_bwd_weight_multi(problems)
+    first = [(gw.clone(), None if gb is None else gb.clone()) for gw, gb in first]
+    for _ in range(150):
+        again = dense.linear_bwd_weight_multi(problems)
+        for (gw0, gb0), (gw1, gb1) in zip(first, again):
+            assert torch.equal(gw0, gw1)
+            assert gb0 is None or torch.equal(gb0, gb1)
+
+
 @pytest.mark.parametrize("m,k0,k1,n,n2", [(60000, 256, 256, 256, 256), (60000, 4, 4, 256, 256), (49999, 132, 0, 256, 64),
                                           (60000, 256, 0, 132, 4), (1000, 64, 64, 256, 256), (120000, 256, 256, 256, 256)])
 def test_chained_layer_gemms_equal_two_calls_bit_for_bit(m, k0, k1, n, n2):
