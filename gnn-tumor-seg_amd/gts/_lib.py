@@ -10,7 +10,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgts_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "gts_hip.h")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -76,12 +76,39 @@ SIGNATURES = {
     "gts_get_option": [_i32],
     "gts_weighted_ce_workspace": [_i64],
     "gts_weighted_ce_f32": [_p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p],
+    "gts_collate_plan": [_p, _i32, _i64, _p, _i32, _p],
+    "gts_collate_batch": [_p, _i32, _i64, _p, _i32, _p, _i64, _i32, _p],
 }
 _RESTYPE = {"gts_error_string": ctypes.c_char_p, "gts_linear_bwd_weight_workspace": _i64,
             "gts_weighted_ce_workspace": _i64, "gts_gat_reduce_workspace": _i64,
             "gts_label_confusion_workspace": _i64, "gts_gat_fc_scores_workspace": _i64,
             "gts_relu_bits_bytes": _i64, "gts_cluster_record_words": _i64, "gts_sage_pool_stack_fwd_arena": _i64, "gts_sage_pool_stack_bwd_scratch": _i64, "gts_cluster_lds_bytes": _i64,
             "gts_linear_bwd_input_t_act_workspace": _i64, "gts_gat_cluster_workspace": _i64}
+
+COLLATE_MAX_SCHEDULES = 6      # GTS_COLLATE_MAX_SCHEDULES
+
+
+class CollateMember(ctypes.Structure):
+    """gts_collate_member_t (include/gts_hip.h): one member of a batch, host pointers."""
+    _fields_ = [("n_nodes", _i64), ("n_edges", _i64),
+                ("indptr", _p), ("indices", _p), ("t_indptr", _p), ("t_indices", _p), ("t_slot", _p), ("t_pos", _p),
+                ("features", _p), ("labels", _p), ("feat_bytes", _i32), ("label_bytes", _i32),
+                ("sched_rec", _p * COLLATE_MAX_SCHEDULES), ("sched_clusters", _i64 * COLLATE_MAX_SCHEDULES),
+                ("sched_loc_words", _i32 * COLLATE_MAX_SCHEDULES)]
+
+
+class CollateKind(ctypes.Structure):
+    """gts_collate_kind_t: the limits one kind of cluster schedule was built with."""
+    _fields_ = [("max_rows", _i32), ("max_srcs", _i32), ("tagged", _i32), ("reserved", _i32)]
+
+
+class CollatePlan(ctypes.Structure):
+    """gts_collate_plan_t: sizes and byte offsets of the collated block."""
+    _fields_ = [("total_bytes", _i64), ("n_nodes", _i64), ("n_edges", _i64), ("features", _i64), ("labels", _i64),
+                ("csr", _i64 * 8), ("sched", _i64 * COLLATE_MAX_SCHEDULES),
+                ("sched_clusters", _i64 * COLLATE_MAX_SCHEDULES), ("sched_loc_words", _i32 * COLLATE_MAX_SCHEDULES),
+                ("sched_record_words", _i32 * COLLATE_MAX_SCHEDULES)]
+
 
 _lib = None
 

@@ -58,6 +58,20 @@ class PinnedRing:
             # once, with room to spare (the slab is idle here: its last copies have completed).
             self.slabs[self.cur] = torch.empty(self.wanted + self.wanted // 2, dtype=torch.uint8, pin_memory=True)
 
+    def reserve(self, nbytes):
+        """`nbytes` of the current slab as a uint8 tensor for the caller to fill in place (gts.collate: the C collate
+        writes a whole batch there and uploads it with one copy).  A slab that is too small is replaced once, with
+        room to spare, when it is still untouched; otherwise the block gets page-locked memory of its own."""
+        start = (self.at + 255) & ~255
+        if start + nbytes > self.slabs[self.cur].numel():
+            if self.at != 0:
+                return torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+            self.slabs[self.cur] = torch.empty(nbytes + nbytes // 2, dtype=torch.uint8, pin_memory=True)
+            start = 0
+        self.at = start + nbytes
+        self.wanted = max(self.wanted, self.at)
+        return self.slabs[self.cur][start:start + nbytes]
+
     def upload(self, host, device):
         nbytes = host.numel() * host.element_size()
         start = (self.at + 255) & ~255
@@ -125,6 +139,18 @@ class _DeviceCSR:
         self.deg_clamped = views[6].view(torch.float32)
         self.deg_plus1 = views[7].view(torch.float32)
 
+    @classmethod
+    def from_views(cls, packed, views, device):
+        """Device CSR over arrays that are on the device already (gts.collate: views of one uploaded block, in
+        _INT_FIELDS order, then max(deg, 1) and deg + 1 as fp32 bits)."""
+        self = cls.__new__(cls)
+        self.device, self.schedules, self.packed = device, {}, packed
+        for name, v in zip(cls._INT_FIELDS, views):
+            setattr(self, name, v)
+        self.deg_clamped = views[6].view(torch.float32)
+        self.deg_plus1 = views[7].view(torch.float32)
+        return self
+
     def record_stream(self, stream):
         """The buffer was uploaded on another stream than the one that will read it."""
         self.packed.record_stream(stream)
@@ -141,6 +167,13 @@ class _DeviceSchedule:
         self.host = sched
         owner = sched.owner if sched.owner is not None else torch.from_numpy(sched.rec)
         self.packed = _upload(owner, device).view(sched.rec.shape)
+
+    @classmethod
+    def from_view(cls, sched, records):
+        """Records that are on the device already (gts.collate); `sched` describes them (n_clusters, limits, ...)."""
+        self = cls.__new__(cls)
+        self.host, self.packed = sched, records
+        return self
 
 
 class Graph:
@@ -248,7 +281,7 @@ class Graph:
         device = torch.device(device)
         if device.type == "cuda" and device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        out = Graph.__new__(Graph)
+        out = type(self).__new__(type(self))
         out.__dict__.update(self.__dict__)
         out.device = device
         out._dev = None

@@ -28,6 +28,7 @@ from torch.utils.data import DataLoader
 
 from data_processing.data_loader import ImageGraphDataset, minibatch_graphs
 from data_processing.graph_io import project_nodes_to_img
+from gts import collate as gcollate
 from gts import dense as gdense
 from gts import dist as gdist
 from gts import nn as gnn
@@ -59,14 +60,18 @@ class _ShardedBatches:
         g = self.per_rank * self.world
         return (len(self.dataset) + g - 1) // g
 
-    def __iter__(self):
+    def raw(self):
+        """One epoch as lists of samples (None: no share of a short global batch), not yet collated."""
         gen = torch.Generator()
         gen.manual_seed(self.seed + self.epoch)
         self.epoch += 1
         perm = torch.randperm(len(self.dataset), generator=gen).tolist()
         for step in range(len(self)):
             idx = gdist.shard_indices(perm, step, self.per_rank, self.rank, self.world)
-            yield minibatch_graphs([self.dataset[i] for i in idx]) if idx else None
+            yield [self.dataset[i] for i in idx] if idx else None
+
+    def __iter__(self):
+        return (None if samples is None else minibatch_graphs(samples) for samples in self.raw())
 
 
 class GNN:
@@ -77,11 +82,14 @@ class GNN:
     ranks instead (per-rank batch ceil(batch_size / W), same optimisation problem as one GPU)."""
 
     def __init__(self, model_type, hyperparameters, train_dataset, batch_size=BATCH_SIZE, prefetch=True,
-                 keep_global_batch=False):
+                 keep_global_batch=False, host_collate=True):
         if not torch.cuda.is_available():
             raise RuntimeError("GNN needs an AMD GPU (MI355X): the HIP kernels have no CPU fallback")
         self.rank, self.world_size = gdist.world()
         self.prefetch = prefetch
+        # True: the loader's batches are assembled by gts_collate_batch (one host C call, one upload: gts/collate.py);
+        # False: by minibatch_graphs + per-array uploads, the Python path whose bytes the C path is tested against
+        self.host_collate = host_collate and os.environ.get("GTS_HOST_COLLATE", "1") != "0"
         self.device = torch.device("cuda", torch.cuda.current_device())
         print("Using device", self.device)
         class_weights = torch.FloatTensor(hyperparameters.class_weights).to(self.device)
@@ -183,12 +191,44 @@ class GNN:
             wanted += ("gat_in", "gat_edge_in", "gat_out")
         return wanted
 
+    def _raw_batches(self):
+        """The training loader's batches as lists of samples (None: an empty share), in the loader's order and drawing
+        from the same random streams, or None when the loader is not one this class built (then it is iterated as is)."""
+        loader = self.train_loader
+        if isinstance(loader, _ShardedBatches):
+            return loader.raw()
+        if isinstance(loader, DataLoader) and loader.collate_fn is minibatch_graphs and loader.num_workers == 0:
+            # the iterator binds the collate function when it is created: the loader itself is left as it was
+            loader.collate_fn = list
+            try:
+                return iter(loader)
+            finally:
+                loader.collate_fn = minibatch_graphs
+        return None
+
     def _device_batches(self):
         """The loader's batches, already on the GPU, prepared one step ahead: a worker thread
         collates batch i+1 (JSON / cache read, block-diagonal union) and uploads it on a copy
         stream while the main thread enqueues step i.  Same batches in the same order as iterating
-        the loader directly (`prefetch=False`)."""
+        the loader directly (`prefetch=False`).
+
+        With `host_collate` (the default) a batch is assembled by ONE host C call into a page-locked slab and uploaded
+        by ONE copy (gts/collate.py): the worker holds the interpreter lock for tens of microseconds per batch."""
+        raw = self._raw_batches() if self.host_collate else None
+        if self._pinned_ring is None and (raw is not None or self.prefetch):
+            self._pinned_ring = PinnedRing()       # page-locked staging slabs: allocated once per GNN, reused every batch
+        ring = self._pinned_ring
+        collator = gcollate.HostCollator(self.device, ring, self._schedules_wanted) if raw is not None else None
         if not self.prefetch:
+            if collator is not None:
+                for samples in raw:
+                    if samples is None:
+                        yield None
+                        continue
+                    _ids, graph, feats, labels = collator(samples)
+                    ring.next_batch()
+                    yield graph, feats, labels
+                return
             for item in self.train_loader:
                 yield None if item is None else self._to_device(*item[1:])
             return
@@ -206,28 +246,30 @@ class GNN:
         def produce():
             try:
                 torch.cuda.set_device(device_index)
-                if self._pinned_ring is None:          # page-locked staging slabs: allocated once per GNN, reused every batch
-                    self._pinned_ring = PinnedRing()
-                uploads_through(self._pinned_ring)
-                for item in self.train_loader:
+                uploads_through(ring)
+                for item in (raw if raw is not None else self.train_loader):
                     if stop.is_set():
                         return
                     if item is None:                       # no share of this (short) global batch
                         slots.put((None, None))
                         continue
-                    _ids, graph, feats, labels = item
                     t0 = time.perf_counter()
                     with torch.cuda.stream(copy_stream):
-                        batch = self._to_device(graph, feats, labels)
-                        t1 = time.perf_counter()
-                        batch[0].dev()                     # CSR upload belongs to the copy as well
-                        t2 = time.perf_counter()
-                        for which in self._schedules_wanted(batch[0].n):
-                            batch[0].dev_schedule(which)   # ... and so do the cluster row schedules the step will read
-                        t3 = time.perf_counter()
+                        if collator is not None:
+                            batch = collator(item)[1:]
+                            t1 = t2 = t3 = time.perf_counter()
+                        else:
+                            _ids, graph, feats, labels = item
+                            batch = self._to_device(graph, feats, labels)
+                            t1 = time.perf_counter()
+                            batch[0].dev()                     # CSR upload belongs to the copy as well
+                            t2 = time.perf_counter()
+                            for which in self._schedules_wanted(batch[0].n):
+                                batch[0].dev_schedule(which)   # ... and so do the cluster row schedules the step will read
+                            t3 = time.perf_counter()
                         ready = torch.cuda.Event()
                         ready.record(copy_stream)
-                        self._pinned_ring.next_batch()
+                        ring.next_batch()
                         t4 = time.perf_counter()
                     slots.put((batch, ready))
                     if trace is not None:
@@ -259,8 +301,9 @@ class GNN:
         finally:
             if trace:
                 mean = [1e3 * sum(col) / len(trace) for col in zip(*trace)]
-                print("[gts prefetch] ms per batch: loader %.2f | features+labels %.2f | csr %.2f | schedules %.2f | event+ring %.2f | "
-                      "queue %.2f  (%d batches)" % (*mean, len(trace)), file=sys.stderr, flush=True)
+                print("[gts prefetch] ms per batch: loader %.2f | %s %.2f | csr %.2f | schedules %.2f | event+ring %.2f | "
+                      "queue %.2f  (%d batches)" % (mean[0], "host collate + upload" if collator is not None else "features+labels",
+                                                    *mean[1:], len(trace)), file=sys.stderr, flush=True)
             stop.set()
             while worker.is_alive():                       # unblock a producer waiting on a full queue
                 try:

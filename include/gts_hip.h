@@ -442,6 +442,63 @@ int32_t gts_set_option(int32_t option, int32_t value);
 /* Current value of a knob (INT32_MIN for an unknown option): callers that change one temporarily put it back. */
 int32_t gts_get_option(int32_t option);
 
+/* ---- K9h: batch collate on the host, straight into the upload layout ---------------------------------
+ * HOST functions (host pointers, no GPU call, no allocation, no state; safe to call from any thread — a
+ * ctypes caller holds no interpreter lock while they run).
+ * Replace, for the training loader's hot path, what the reference does per step in
+ * data_processing/data_loader.py:165-169 (`minibatch_graphs`: dgl.batch + np.concatenate of the
+ * members' features and labels + FloatTensor / LongTensor conversions) and model/gnn_model.py:37-40
+ * (`.to(device)` of graph, features, labels): the members' cached host arrays are written ONCE, already
+ * shifted / converted, into one caller-owned (page-locked) block laid out exactly as the device will
+ * read it, so that a batch reaches the GPU in ONE asynchronous copy:
+ *
+ *   features fp32 [N, feat_width] | labels int64 [N] |
+ *   indptr [N+1] | indices [E] | t_indptr [N+1] | t_indices [E] | t_slot [E] | t_pos [E] |
+ *   max(in-degree, 1) fp32 [N] | in-degree + 1 fp32 [N] |
+ *   cluster-schedule records of kind 0 | kind 1 | ...        (every segment 256-byte aligned)
+ *
+ * Block-diagonal union as dgl.batch defines it: node ids of member j shifted by sum_{i<j} N_i, edges
+ * (and CSR positions) by sum_{i<j} E_i, members in order; fp64 features are rounded to fp32 as
+ * torch.FloatTensor(np.concatenate(features)) rounds them; labels widen to int64.  Schedule records
+ * (gts_cluster_schedule) are concatenated member by member with their row / neighbour ids shifted and
+ * their per-edge sections re-packed to the widest member's loc_words.  The bytes equal what the Python
+ * path (gts.batch + ClusterSchedule.concat, the tested reference) produces: tests/test_collate_host.py.
+ *
+ * gts_collate_plan fills `plan` (sizes and byte offsets) for `members`; gts_collate_batch writes the block
+ * (`dst_bytes` >= plan.total_bytes) using up to `n_threads` threads of its own (<= 1: the calling thread only).
+ * A schedule kind that some member lacks (sched_rec NULL) is dropped for the whole batch (plan.sched_clusters
+ * = -1).  Returns GTS_OK, GTS_ERR_NULL, GTS_ERR_SHAPE (sizes beyond int32, dst too small, members whose
+ * records do not match the kind's limits) or GTS_ERR_ARGKIND (feature / label element kinds). */
+#define GTS_COLLATE_MAX_SCHEDULES 6
+typedef struct {
+  int64_t n_nodes, n_edges;
+  const int32_t *indptr, *indices, *t_indptr, *t_indices, *t_slot, *t_pos;
+  const void* features;     /* [n_nodes, feat_width] row-major */
+  const void* labels;       /* [n_nodes], or NULL when the batch carries none */
+  int32_t feat_bytes;       /* 4 = fp32, 8 = fp64 */
+  int32_t label_bytes;      /* 8 = int64, 4 = int32 (0 with labels == NULL) */
+  const int32_t* sched_rec[GTS_COLLATE_MAX_SCHEDULES];   /* [clusters, record words] per kind, or NULL */
+  int64_t sched_clusters[GTS_COLLATE_MAX_SCHEDULES];
+  int32_t sched_loc_words[GTS_COLLATE_MAX_SCHEDULES];
+} gts_collate_member_t;
+typedef struct {
+  int32_t max_rows, max_srcs, tagged, reserved;          /* the limits the kind's records were built with */
+} gts_collate_kind_t;
+typedef struct {
+  int64_t total_bytes, n_nodes, n_edges;
+  int64_t features, labels;                              /* byte offsets; labels = -1 when absent */
+  int64_t csr[8];                                        /* indptr, indices, t_indptr, t_indices, t_slot, t_pos, deg_clamped, deg_plus1 */
+  int64_t sched[GTS_COLLATE_MAX_SCHEDULES];              /* byte offset of each kind's records (-1: dropped) */
+  int64_t sched_clusters[GTS_COLLATE_MAX_SCHEDULES];     /* clusters of the union (-1: dropped) */
+  int32_t sched_loc_words[GTS_COLLATE_MAX_SCHEDULES];    /* loc_words of the union's records */
+  int32_t sched_record_words[GTS_COLLATE_MAX_SCHEDULES];
+} gts_collate_plan_t;
+int32_t gts_collate_plan(const gts_collate_member_t* members, int32_t n_members, int64_t feat_width,
+                         const gts_collate_kind_t* kinds, int32_t n_kinds, gts_collate_plan_t* plan);
+int32_t gts_collate_batch(const gts_collate_member_t* members, int32_t n_members, int64_t feat_width,
+                          const gts_collate_kind_t* kinds, int32_t n_kinds, void* dst, int64_t dst_bytes,
+                          int32_t n_threads, gts_collate_plan_t* plan);
+
 #ifdef __cplusplus
 }
 #endif

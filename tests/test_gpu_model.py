@@ -541,13 +541,15 @@ def test_prefetched_epochs_equal_plain_epochs_and_errors_surface():
 
     hp = FullParamSet(3, 20, 4, 1e-3, 0.98, 1e-4, [0.1, 1, 2, 2], [64, 64], 0, None, None)
     results = []
-    for prefetch in (True, False):
+    # host_collate: batches assembled by gts_collate_batch (one C call, one upload) vs the Python collate + per-array uploads
+    for prefetch, host_collate in ((True, True), (False, False), (False, True), (True, False)):
         torch.manual_seed(5)
-        model = GNN("GSpool", hp, _MemDataset(14), batch_size=3, prefetch=prefetch)
+        model = GNN("GSpool", hp, _MemDataset(14), batch_size=3, prefetch=prefetch, host_collate=host_collate)
         losses = [model.run_epoch() for _ in range(3)]
         results.append((losses, [p.detach().clone() for p in model.net.parameters()]))
-    assert results[0][0] == results[1][0]
-    assert all(torch.equal(a, b) for a, b in zip(results[0][1], results[1][1]))
+    for other in results[1:]:
+        assert results[0][0] == other[0]
+        assert all(torch.equal(a, b) for a, b in zip(results[0][1], other[1]))
 
     class Broken(_MemDataset):
         def __getitem__(self, i):
@@ -565,6 +567,47 @@ def test_prefetched_epochs_equal_plain_epochs_and_errors_surface():
     next(batches)
     batches.close()
     assert np.isfinite(model.run_epoch())
+
+
+def test_host_collated_batch_on_the_device_equals_the_python_collate():
+    """gts.collate.HostCollator: one C call + one upload; every device array the kernels read (features, labels, both CSRs,
+    degree vectors, the 'in' / 'out' schedule records) equals what minibatch_graphs + Graph.dev() + dev_schedule() upload,
+    and a 256-wide pool layer run over either graph gives the same bits (the clustered K2 reads the collated records)."""
+    from data_processing.data_loader import minibatch_graphs
+    from gts import collate
+    from gts.graph import PinnedRing
+
+    dims = [(12, 12, 12), (13, 12, 11), (12, 11, 10)]
+    samples = [(f"s{i}", synth.lattice_graph(d), synth.node_features(int(np.prod(d)), 20, i).astype(np.float64),
+                synth.node_labels(int(np.prod(d)), i)) for i, d in enumerate(dims)]
+    ring = PinnedRing(slabs=2, nbytes=1 << 16)          # too small on purpose: reserve() replaces the slab
+    dev = torch.device("cuda", torch.cuda.current_device())
+    col = collate.HostCollator(dev, ring, lambda n_rows: ("out", "in"))
+    for _ in range(3):                                   # slabs are reused: the bytes must be right every time round
+        ids, g, feats, labels = col(samples)
+        ring.next_batch()
+        rids, rg, rfeats, rlabels = minibatch_graphs(samples)
+        rg = rg.to(DEV)
+        assert ids == rids and torch.equal(feats.cpu(), rfeats) and torch.equal(labels.cpu(), rlabels)
+        d, rd = g.dev(), rg.dev()
+        for name in ("indptr", "indices", "t_indptr", "t_indices", "t_slot", "t_pos", "deg_clamped", "deg_plus1"):
+            assert torch.equal(getattr(d, name), getattr(rd, name)), name
+        for which in ("in", "out"):
+            a, b = g.dev_schedule(which), rg.dev_schedule(which)
+            assert a is not None and b is not None
+            assert torch.equal(a.packed, b.packed) and a.host.n_clusters == b.host.n_clusters
+            assert (a.host.limits, a.host.loc_words, a.host.tagged) == (b.host.limits, b.host.loc_words, b.host.tagged)
+    torch.manual_seed(0)
+    layer = gnn.SAGEConv(256, 256, "pool", activation=F.relu).to(DEV)
+    x = torch.randn(g.n, 256, device=DEV)
+    outs = []
+    for graph in (g, rg):
+        xi = x.clone().requires_grad_(True)
+        y = layer(graph, xi)
+        y.square().sum().backward()
+        outs.append((y.detach(), xi.grad))
+        layer.zero_grad()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 def test_pinned_ring_grows_a_slab_a_batch_has_outgrown_and_keeps_the_bytes():

@@ -42,22 +42,27 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--graph-kind", default="lattice")
     ap.add_argument("--config", default="c2", choices=["c2", "real"])
+    ap.add_argument("--epochs", type=int, default=3, help="timed epochs per mode (after one warm-up epoch)")
     args = ap.parse_args()
     cfg = bench.CONFIGS[args.config]
     args.batch = args.batch or cfg.get("graphs_per_gpu", 4)
     data = MemDataset(args.samples, args.graph_kind, cfg)
-    for prefetch in (False, True, False, True):
+    modes = [(False, False), (False, True), (True, False), (True, True)] * 2     # (prefetch thread, C host collate)
+    for prefetch, host_collate in modes:
         torch.manual_seed(0)
         with contextlib.redirect_stdout(sys.stderr):
-            model = GNN(cfg["model"], bench.hyperparams(cfg), data, batch_size=args.batch, prefetch=prefetch)
+            model = GNN(cfg["model"], bench.hyperparams(cfg), data, batch_size=args.batch, prefetch=prefetch,
+                        host_collate=host_collate)
         model.run_epoch()                                   # warm-up epoch
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        loss = model.run_epoch()
+        for _ in range(args.epochs):
+            loss = model.run_epoch()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        steps = len(model.train_loader)
-        print(json.dumps({"config": args.config, "batch": args.batch, "prefetch": prefetch, "graphs_per_s": round(steps * args.batch / dt, 1),
+        steps = len(model.train_loader) * args.epochs
+        print(json.dumps({"config": args.config, "batch": args.batch, "prefetch": prefetch, "host_collate": host_collate,
+                          "graphs_per_s": round(steps * args.batch / dt, 1),
                           "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "epoch_loss": float(loss)}),
               flush=True)
 
