@@ -107,6 +107,7 @@ class GNN:
         self.loss_fcn = lambda logits, labels: gops.weighted_cross_entropy(logits, labels, class_weights)
         self.grad_sync = None
         self._pinned_ring = None
+        self._copy_stream = None
         # the fused layer stack writes its weight gradients straight into one flat buffer laid out like the optimizer's
         # parameters (no per-parameter gradient tensors, nothing to concatenate before the AdamW launch)
         self.grad_sink = gnn.GradSink(self.optimizer._params)
@@ -236,7 +237,9 @@ class GNN:
         import threading
 
         slots, stop = queue.Queue(maxsize=2), threading.Event()
-        copy_stream = torch.cuda.Stream(device=self.device)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        copy_stream = self._copy_stream
         device_index = self.device.index
 
         import time

@@ -6,7 +6,7 @@ TAG=${1:-rXX}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-FLAGS="--steps 20 --warmup 5 --no-cpu-baseline"
+FLAGS="${AB_FLAGS:---steps 20 --warmup 5 --no-cpu-baseline}"
 i=0
 for envs in "$@"; do
   i=$((i+1))

@@ -38,7 +38,7 @@ class MemDataset(torch.utils.data.Dataset):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--samples", type=int, default=48)
+    ap.add_argument("--samples", type=int, default=None, help="default: 48 steps per epoch")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--graph-kind", default="lattice")
     ap.add_argument("--config", default="c2", choices=["c2", "real"])
@@ -46,6 +46,9 @@ def main():
     args = ap.parse_args()
     cfg = bench.CONFIGS[args.config]
     args.batch = args.batch or cfg.get("graphs_per_gpu", 4)
+    args.samples = args.samples or 48 * args.batch
+    if os.environ.get("GTS_SWITCH_INTERVAL"):       # experiment: how long a thread may keep the interpreter lock
+        sys.setswitchinterval(float(os.environ["GTS_SWITCH_INTERVAL"]))
     data = MemDataset(args.samples, args.graph_kind, cfg)
     modes = [(False, False), (False, True), (True, False), (True, True)] * 2     # (prefetch thread, C host collate)
     for prefetch, host_collate in modes:
