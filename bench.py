@@ -96,7 +96,7 @@ def parse_args():
     ap.add_argument("--graph-kind", default="lattice", choices=["lattice", "random", "selfloop"])
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-oracle steps after one warm-up (SURVEY.md §8d: >= 5)")
     args = ap.parse_args()
     if args.graphs_per_gpu is None:
         args.graphs_per_gpu = CONFIGS[args.config].get("graphs_per_gpu", 4)
@@ -385,11 +385,12 @@ def main():
         enqueue = time.perf_counter() - t0      # CPU time to enqueue K steps (no sync inside)
         fence()
         elapsed = time.perf_counter() - t0
+        own = elapsed
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, enqueue, last
+        return elapsed, enqueue, last, own
 
     log(f"rank {rank}/{world}: {args.config} batches resident (N_b={n_b}, E_b={e_b}); warm-up")
     for i in range(args.warmup):
@@ -405,6 +406,15 @@ def main():
     timers.enabled = ops.INSTRUMENTED = True
     instrumented = timed_block()[0]
     timers.enabled = ops.INSTRUMENTED = False
+    # per-rank view (N > 1): every rank's own wall time for the last timed block and the time its all-reduce launches took
+    # (a rank that finishes its graphs early waits there: the spread between ranks IS the load imbalance)
+    per_rank = None
+    if world > 1:
+        ar = timers.summary("all_reduce")
+        mine = torch.tensor([blocks[-1][3], (ar["total_ms"] / ar["launches"]) if ar else 0.0], dtype=torch.float64, device=device)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(everyone, mine)
+        per_rank = [[float(v) for v in t.tolist()] for t in everyone]
     # --config real: the same steps on two RESIDENT batches (every rank; the blocks fence collectively): what the host path costs
     resident = sorted(timed_block(resident_step)[:2] for _ in range(3))[1] if args.config == "real" else None
     log("block seconds in order: " + " ".join(f"{b[0]:.4f}" for b in blocks))
@@ -466,6 +476,11 @@ def main():
         kinds = {k: timers.summary("gemm_" + k) for k in ("fwd", "igrad", "wgrad")}
         kinds = {k: v for k, v in kinds.items() if v}
         sample = f"HIP events around every launch in one extra block of {args.steps} steps after the timed blocks"
+        # the timed blocks issue the SAGE-pool layer stack through the one-call entry points (gts_sage_pool_stack_*_f32);
+        # events need single launches, so the instrumented block issues the same kernels, in the same order, one library
+        # call each (gts/nn.py::_SagePoolStack) — same device work, more host calls
+        path = ("launch-by-launch: one C-ABI call per kernel (the timed blocks enqueue the same launches through "
+                "gts_sage_pool_stack_fwd_f32 / _bwd_f32)") if cfg["model"] == "GSpool" else "as in the timed blocks"
         if kinds:
             flops = sum(v["work"] for v in kinds.values())
             secs = sum(v["total_ms"] for v in kinds.values()) * 1e-3
@@ -478,7 +493,7 @@ def main():
                 "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                 "flops_per_step": flops / args.steps, "gemm_ms_per_step": round(1e3 * secs / args.steps, 4),
-                "share_of_step": round(secs / instrumented, 3),
+                "share_of_step": round(secs / instrumented, 3), "path": path,
                 "by_kind": {k: {"launches_per_step": v["launches"] / args.steps,
                                 "avg_launch_us": round(1e3 * v["total_ms"] / v["launches"], 2),
                                 "tflops": round(v["work"] / (v["total_ms"] * 1e-3) / 1e12, 1)}
@@ -491,7 +506,8 @@ def main():
             "spmm_max_bwd_f256": "gts_spmm_max_bwd_cluster_f32: spmm_cluster_stream_kernel<bwd>, else gts_spmm_max_bwd_f32",
             "gat_fwd": "gts_gat_fwd_cluster_f32: gat_weights_one_chunk_kernel (edge softmax) + gat_cluster_stream_kernel<fwd>, "
                        "else gts_gat_fwd_f32",
-            "gat_bwd_edge": "gts_gat_bwd_edge_f32: gat_bwd_edge_kernel",
+            "gat_bwd_edge": "gts_gat_bwd_edge_cluster_f32: gat_cluster_stream_kernel<edge> + gat_edge_finish_kernel (graphs with a "
+                            "'gat_edge_in' schedule: in-degree <= 8, >= 20 000 rows), else gts_gat_bwd_edge_f32: gat_bwd_edge_kernel",
             "gat_bwd_src": "gts_gat_bwd_src_cluster_f32: gat_weights_one_chunk_kernel + gat_cluster_stream_kernel<bwd>, "
                            "else gts_gat_bwd_src_f32",
             "project_rows": "gts_project_rows_i16: project_rows_kernel",
@@ -515,7 +531,7 @@ def main():
                         "algorithmic_bytes_per_launch": alg,
                         "algorithmic_gbs": round(alg / (us * 1e-6) / 1e9, 1),
                         "avg_launch_us": round(us, 2), "launches_timed": s["launches"],
-                        "rocprof_avg_launch_us": rocprof_us, "rocprof_source": rsource, "sample": sample})
+                        "rocprof_avg_launch_us": rocprof_us, "rocprof_source": rsource, "sample": sample, "path": path})
         result["roofline_hbm"] = hbm
         if "roofline" not in result and hbm:
             result["roofline"] = hbm[0]
@@ -524,6 +540,14 @@ def main():
             result["all_reduce"] = {"payload_bytes": int(model.grad_sync.flat.numel() * 4),
                                     "avg_us": round(1e3 * ar["total_ms"] / ar["launches"], 1),
                                     "launches_timed": ar["launches"]}
+        if per_rank is not None:
+            step_ms = [1e3 * r[0] / args.steps for r in per_rank]
+            result["per_rank"] = {"step_ms": [round(v, 4) for v in step_ms], "step_ms_max": round(max(step_ms), 4),
+                                  "step_ms_min": round(min(step_ms), 4),
+                                  "all_reduce_us": [round(1e3 * r[1], 1) for r in per_rank],
+                                  "note": "own wall time per step of the last timed block (fences on both sides), and the mean "
+                                          "duration of the rank's all-reduce launches in the instrumented block: a rank with "
+                                          "less work waits longer inside the collective"}
         if world == 1 and not args.no_cpu_baseline and args.config != "c5":
             cpu_steps = 1 if args.config == "c3" else args.cpu_steps   # a GAT step takes ~1 min on the CPU
             result["cpu_baseline"] = cpu_baseline(cfg, args.graphs_per_gpu, args.graph_kind, cpu_steps)

@@ -509,6 +509,17 @@ extern "C" int32_t gts_cluster_schedule(const int32_t* indptr, const int32_t* in
   if (max_rows < 1 || max_srcs < 1 || max_srcs > 256 || max_edges < 1 || max_edges > 65535) return GTS_ERR_ARGKIND;
   const int n = static_cast<int>(n_rows);
   if (n > 0 && (!indices || !t_indices) && indptr[n] > 0) return GTS_ERR_NULL;
+  // a malformed CSR must come back as an error, not as reads and writes outside the builder's tables: row extents
+  // ascending from 0, the transpose with the same edge total, every id inside [0, n)
+  if (n > 0) {
+    if (indptr[0] != 0 || t_indptr[0] != 0) return GTS_ERR_SHAPE;
+    for (int v = 0; v < n; ++v)
+      if (indptr[v + 1] < indptr[v] || t_indptr[v + 1] < t_indptr[v]) return GTS_ERR_SHAPE;
+    if (indptr[n] != t_indptr[n]) return GTS_ERR_SHAPE;
+    const int e_all = indptr[n];
+    for (int k = 0; k < e_all; ++k)
+      if (indices[k] < 0 || indices[k] >= n || t_indices[k] < 0 || t_indices[k] >= n) return GTS_ERR_SHAPE;
+  }
   for (int v = 0; v < n; ++v) {   // every row must fit a cluster of its own
     const int deg = indptr[v + 1] - indptr[v];
     if (deg > max_srcs || ((deg + 7) & ~7) > max_edges || deg > 65535) return GTS_ERR_SHAPE;

@@ -48,6 +48,11 @@ class ImageGraphDataset(torch.utils.data.Dataset):
     def _path(self, mri_id, suffix):
         return f"{self.dataset_root_dir}{os.sep}{mri_id}{os.sep}{mri_id}{suffix}"
 
+    def sample_costs(self):
+        """One cost per sample for size-aware sharding under data parallelism (gts.dist.shard_indices): the bytes of
+        its node-link JSON — proportional to nodes + edges, known without parsing anything, the same on every rank."""
+        return [os.path.getsize(self._path(mri_id, "_nxgraph.json")) if self.read_graph else 1 for mri_id in self.all_ids]
+
     def get_one(self, mri_id):
         parts = []
         if self.read_graph:

@@ -58,12 +58,47 @@ def init_from_env(backend=None):
     return rank, world_size, local_rank
 
 
-def shard_indices(perm, step, per_rank, rank, world_size):
+def shard_indices(perm, step, per_rank, rank, world_size, costs=None):
     """Indices of rank `rank` for global step `step`: the global batch is
-    perm[step*G:(step+1)*G] with G = per_rank*world_size, dealt round-robin (r::W).  The last
-    global batch of an epoch may be short; a rank whose share of it is empty gets []."""
+    perm[step*G:(step+1)*G] with G = per_rank*world_size.  The last global batch of an epoch may be
+    short; a rank whose share of it is empty gets [].
+
+    costs is None: dealt round-robin (r::W) — right when every graph costs the same (the synthetic
+    15k-node graphs of the benchmark).
+    costs[i] = cost of dataset item i (node count, or a proxy such as the size of its graph file): the
+    global batch — the SAME set of graphs, hence the same exact gradient after the all-reduce — is
+    dealt by longest-processing-time: graphs in order of falling cost (ties: position in the batch) go
+    to the rank with the least cost so far that still has room (at most `per_rank` graphs; ties: lowest
+    rank).  Real supervoxel graphs have 5 - 7k nodes (/root/reference/mri2graph/graphgen.py:210-211): dealt
+    blindly, every step waits for the rank that drew the largest ones.  Deterministic, no communication:
+    every rank computes the whole deal.  A rank's graphs keep their order in the global batch."""
     g = per_rank * world_size
-    return list(perm[step * g:(step + 1) * g][rank::world_size])
+    chunk = list(perm[step * g:(step + 1) * g])
+    if costs is None or world_size == 1:
+        return chunk[rank::world_size]
+    order = sorted(range(len(chunk)), key=lambda k: (-costs[chunk[k]], k))
+    load, held = [0] * world_size, [[] for _ in range(world_size)]
+    for k in order:
+        r = min((r for r in range(world_size) if len(held[r]) < per_rank), key=lambda r: (load[r], r))
+        held[r].append(k)
+        load[r] += costs[chunk[k]]
+    return [chunk[k] for k in sorted(held[rank])]
+
+
+def sample_costs(dataset):
+    """Per-item cost of `dataset` for shard_indices, identical on every rank, WITHOUT loading the samples: the
+    dataset's own `sample_costs()` (ImageGraphDataset: bytes of each graph file; in-memory datasets: node counts),
+    followed through torch Subsets.  None when the dataset offers none (round-robin dealing then)."""
+    indices = None
+    while hasattr(dataset, "dataset") and hasattr(dataset, "indices"):        # torch.utils.data.Subset
+        own = list(dataset.indices)
+        indices = own if indices is None else [own[i] for i in indices]
+        dataset = dataset.dataset
+    fn = getattr(dataset, "sample_costs", None)
+    if fn is None:
+        return None
+    costs = list(fn())
+    return costs if indices is None else [costs[i] for i in indices]
 
 
 def rank_share(n_items):

@@ -359,12 +359,14 @@ _stack_tables = {}   # (parameter storage addresses) -> (pointer table, widths) 
 def _stack_table(params, in_feats):
     import ctypes
 
-    key = (in_feats, *[p.data_ptr() for p in params])
+    # addresses AND shapes: the caching allocator may hand a freed network's addresses to one with other widths
+    ptrs = [p.data_ptr() for p in params]
+    key = (in_feats, *ptrs, *[tuple(p.shape) for p in params])
     hit = _stack_tables.get(key)
     if hit is None:
         n_layers = len(params) // 5
         widths = [in_feats] + [params[5 * i + 2].shape[0] for i in range(n_layers)]
-        hit = ((ctypes.c_void_p * (5 * n_layers))(*key[1:]), (ctypes.c_int64 * (n_layers + 1))(*widths), widths)
+        hit = ((ctypes.c_void_p * (5 * n_layers))(*ptrs), (ctypes.c_int64 * (n_layers + 1))(*widths), widths)
         if len(_stack_tables) > 64:
             _stack_tables.clear()
         _stack_tables[key] = hit
@@ -427,7 +429,11 @@ class _SagePoolStackCall(torch.autograd.Function):
         gout = gout.contiguous()
         d = g.dev()
         sink = _active_sink
-        if sink is not None and not all(i in sink.offsets for i in ctx.param_ids):
+        # the sink stands for the optimizer's WHOLE flat gradient: it is used only when this stack holds exactly its
+        # parameters.  A network with parameters outside the stack gets ordinary per-parameter gradients (views of one
+        # buffer) from this node, and autograd fills in the rest — nothing is dropped silently.
+        if sink is not None and (len(ctx.param_ids) != len(sink.params) or
+                                 not all(i in sink.offsets for i in ctx.param_ids)):
             sink = None
         sizes = [p.numel() for p in params]
         if sink is not None:
@@ -451,7 +457,7 @@ class _SagePoolStackCall(torch.autograd.Function):
             c_widths, n_layers, ab, flags, arena.data_ptr(), grads, ptr(gx), scratch.data_ptr(), int(need),
             current_stream()), "gts_sage_pool_stack_bwd_f32")
         if sink is not None:
-            sink.filled = len(ctx.param_ids) == len(sink.params)
+            sink.filled = True
             return (None, gx, None, *([None] * len(params)))
         return (None, gx, None, *[flat[s:s + k].view_as(p) for s, k, p in zip(starts, sizes, params)])
 
@@ -573,11 +579,16 @@ class ActLink:
     sums the producer's bias gradient there (`dense.linear_bwd_input_t_act`), and the producer skips its own pass over
     [N, H*D] (`ops.gat_act_bwd`: three tensors of 245 MB at the C3 shapes).  Same g_pre bit for bit; the bias gradient is
     summed in a different fixed order.  The gradient autograd hands from consumer to producer is then d loss / d
-    (pre-activation): do not link a layer whose output anything else reads."""
-    __slots__ = ("folded", "g_bias")
+    (pre-activation): do not link a layer whose output anything else reads.
+
+    The link is two-sided: the PRODUCER arms it (`armed` = the activation code it will skip in its backward: 1 = ELU) only
+    when it runs as the fused node with that activation and a backward; the consumer folds only through an armed link and
+    with the producer's code.  A producer on the op-by-op path, with another activation callable or with none leaves the
+    link unarmed, and both layers run their own backward passes."""
+    __slots__ = ("folded", "g_bias", "armed")
 
     def __init__(self):
-        self.folded, self.g_bias = False, None
+        self.folded, self.g_bias, self.armed = False, None, 0
 
 
 class _GATLayer(torch.autograd.Function):
@@ -607,6 +618,8 @@ class _GATLayer(torch.autograd.Function):
             ctx.save_for_backward(h, ft, el, er, attn, out if act_code else None, w_fc, al, ar, w_res)
             ctx.attn_shape = attn_l.shape
             ctx.below, ctx.above = below, above if act_code == 1 else None
+            if ctx.above is not None:
+                ctx.above.armed = act_code      # this node will skip its activation backward if the consumer folds it
         return out
 
     @staticmethod
@@ -616,7 +629,7 @@ class _GATLayer(torch.autograd.Function):
         need = ctx.needs_input_grad
         if ctx.above is not None and ctx.above.folded:   # the layer above has applied ELU' and summed the bias gradient
             g_pre, g_bias = gout.reshape(n, heads * dim), ctx.above.g_bias if need[5] else None
-            ctx.above.folded, ctx.above.g_bias = False, None
+            ctx.above.folded, ctx.above.g_bias, ctx.above.armed = False, None, 0
         else:
             g_pre, g_bias = ops.gat_act_bwd(gout.reshape(n, heads * dim),
                                             out.view(n, heads * dim) if out is not None else None, ctx.act,
@@ -628,12 +641,13 @@ class _GATLayer(torch.autograd.Function):
         # wide layers: the input gradient runs in the forward GEMM's form on transposed weights
         turn = TRANSPOSED_IGRAD and need[1] and w_fc.shape[1] >= 128 and w_fc.shape[0] % 4 == 0 \
             and w_fc.shape[1] % 4 == 0 and n >= 4096
-        fold = turn and ctx.below is not None and not ctx.identity_res and FOLD_GAT_ACT_BWD
+        fold = turn and ctx.below is not None and ctx.below.armed == 1 and not ctx.identity_res and FOLD_GAT_ACT_BWD
+        act_below = ctx.below.armed if fold else 0
         if w_res is not None:
             (g_wfc, _), (g_wres, _) = dense.linear_bwd_weight_multi([(gft2, h, False), (g_pre, h, False)])
             if fold:
                 wt = dense.transpose_batch([w_fc, w_res])
-                gh, ctx.below.g_bias = dense.linear_bwd_input_t_act(gft2, wt[0], h, 1, g_pre, wt[1])
+                gh, ctx.below.g_bias = dense.linear_bwd_input_t_act(gft2, wt[0], h, act_below, g_pre, wt[1])
                 ctx.below.folded = True
             elif turn:
                 wt = dense.transpose_batch([w_fc, w_res])
@@ -643,7 +657,7 @@ class _GATLayer(torch.autograd.Function):
         else:
             g_wfc, _ = dense.linear_bwd_weight(gft2, h)
             if fold:
-                gh, ctx.below.g_bias = dense.linear_bwd_input_t_act(gft2, dense.transpose_batch([w_fc])[0], h, 1)
+                gh, ctx.below.g_bias = dense.linear_bwd_input_t_act(gft2, dense.transpose_batch([w_fc])[0], h, act_below)
                 ctx.below.folded = True
             elif turn:
                 gh = dense.linear_bwd_input_t(gft2, dense.transpose_batch([w_fc])[0])
@@ -707,6 +721,8 @@ class GATConv(nn.Module):
                                       "model/networks.py:77-78 passes no dropout to GAT)")
         n = feat.shape[0]
         h = self.feat_drop(feat)
+        if above is not None:
+            above.armed = 0                      # armed below only by the fused node that will skip its ELU backward
         act_code = 0 if self.activation is None else 1 if self.activation in (F.elu, torch.nn.functional.elu) else -1
         if FUSE_GAT_LAYER and act_code >= 0 and self._out_feats % 4 == 0 and feat.dim() == 2:
             w_res = self.res_fc.weight if isinstance(self.res_fc, nn.Linear) else None

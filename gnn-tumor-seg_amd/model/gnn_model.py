@@ -44,8 +44,8 @@ EVAL_BATCH_SIZE = 8     # samples per batched evaluation forward (the reference 
 
 
 class _ShardedBatches:
-    """Epoch iterator for data-parallel runs: one shared shuffle, per-rank slices of every global
-    batch of `per_rank * world_size` samples.  Like the reference's `DataLoader(drop_last=False)`
+    """Epoch iterator for data-parallel runs: one shared shuffle, per-rank shares of every global
+    batch of `per_rank * world_size` samples (dealt by cost when the dataset knows its samples' sizes).  Like the reference's `DataLoader(drop_last=False)`
     (model/gnn_model.py:31) the trailing partial global batch IS trained on: it is dealt round-robin
     too, and a rank whose share of it is empty yields None (it then contributes zero gradients and
     zero loss weight to that step's all-reduce, so the weighted-CE normalisation stays exact)."""
@@ -55,6 +55,10 @@ class _ShardedBatches:
         self.seed, self.epoch = seed, 0
         if len(dataset) == 0:
             raise ValueError("the training dataset is empty: an epoch would have no step")
+        # graphs of unequal size are dealt to the ranks by cost inside every global batch (gts.dist.shard_indices)
+        self.costs = gdist.sample_costs(dataset)
+        if self.costs is not None and len(self.costs) != len(dataset):
+            raise ValueError("sample_costs() must return one cost per dataset item")
 
     def __len__(self):
         g = self.per_rank * self.world
@@ -67,7 +71,7 @@ class _ShardedBatches:
         self.epoch += 1
         perm = torch.randperm(len(self.dataset), generator=gen).tolist()
         for step in range(len(self)):
-            idx = gdist.shard_indices(perm, step, self.per_rank, self.rank, self.world)
+            idx = gdist.shard_indices(perm, step, self.per_rank, self.rank, self.world, self.costs)
             yield [self.dataset[i] for i in idx] if idx else None
 
     def __iter__(self):

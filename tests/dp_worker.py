@@ -31,6 +31,25 @@ class MemDataset(torch.utils.data.Dataset):
         return self.items[i]
 
 
+class UnequalDataset(MemDataset):
+    """Graphs of unequal size (50 .. 70 nodes: the 5 - 7k spread of real supervoxel graphs, scaled down) that know their
+    costs, as ImageGraphDataset does through its file sizes."""
+
+    def __init__(self, n_samples, in_feats=20, seed=0):
+        from gts import synth
+
+        sizes = np.random.default_rng(seed).integers(50, 71, size=n_samples)
+        self.items = []
+        for i, n in enumerate(sizes):
+            g = synth.random_graph(n=int(n), n_pairs=2 * int(n), seed=1000 + i)
+            self.items.append((f"s{i}", g, synth.node_features(int(n), in_feats, 1000 + i).astype(np.float64),
+                               synth.node_labels(int(n), 1000 + i)))
+        self.read_label = True
+
+    def sample_costs(self):
+        return [item[1].n for item in self.items]
+
+
 def hyperparams():
     from utils.hyperparam_helpers import FullParamSet
 

@@ -36,6 +36,26 @@ def test_argument_errors_do_not_need_a_gpu(hip_lib):
     assert hip_lib.gts_spmm_max_fwd_f32(one, one, one, one, None, 0, 1, 0, 4, None) == 0
 
 
+def test_cluster_schedule_rejects_a_malformed_csr(hip_lib):
+    """gts_cluster_schedule is a HOST entry point of the C ABI: ids outside [0, n), extents that go down or that do not
+    match the transpose must come back as GTS_ERR_SHAPE, not index the builder's tables."""
+    import numpy as np
+
+    def run(indptr, indices, t_indptr, t_indices):
+        arrs = [np.asarray(a, dtype=np.int32) for a in (indptr, indices, t_indptr, t_indices)]
+        out = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
+        return hip_lib.gts_cluster_schedule(*[a.ctypes.data_as(ctypes.c_void_p) for a in arrs], None, 3, 8, 16, 64, None, 0,
+                                            ctypes.byref(out[0]), ctypes.byref(out[1]), ctypes.byref(out[2]))
+    good = ([0, 1, 2, 3], [1, 2, 0], [0, 1, 2, 3], [2, 0, 1])
+    assert run(*good) == 0
+    assert run([0, 1, 2, 3], [1, 7, 0], good[2], good[3]) == -2            # neighbour id past the last row
+    assert run([0, 1, 2, 3], [1, -1, 0], good[2], good[3]) == -2
+    assert run(good[0], good[1], [0, 1, 2, 3], [2, 0, 3]) == -2            # ... in the transpose
+    assert run([0, 2, 1, 3], good[1], good[2], good[3]) == -2              # extents go down
+    assert run([0, 1, 2, 3], good[1], [0, 1, 2, 2], good[3]) == -2         # transpose holds another number of edges
+    assert run([1, 1, 2, 3], good[1], good[2], good[3]) == -2              # extents do not start at 0
+
+
 def test_product_refuses_cpu_tensors(hip_lib):
     import numpy as np
     import pytest

@@ -136,6 +136,97 @@ def test_shard_indices_partition():
             assert got == sorted(perm[step * per_rank * world:(step + 1) * per_rank * world])
 
 
+def test_shard_indices_by_cost_is_a_balanced_partition():
+    """Longest-processing-time dealing inside every global batch: still a partition of the batch, at most `per_rank`
+    graphs per rank, the same answer on every call, a rank's graphs in batch order — and for graphs of 5 - 7k nodes
+    (/root/reference/mri2graph/graphgen.py:210-211) the heaviest rank carries at most 1.1 x the lightest one's nodes,
+    where the blind r::W deal reaches 1.2 and more."""
+    rng = np.random.default_rng(1)
+    costs = rng.integers(5000, 7001, size=96).tolist()
+    perm = rng.permutation(96).tolist()
+    worst_lpt, worst_blind = 1.0, 1.0
+    for world, per_rank in ((2, 6), (4, 6), (8, 6), (2, 3)):
+        g = world * per_rank
+        for step in range(96 // g):
+            shares = [gdist.shard_indices(perm, step, per_rank, r, world, costs) for r in range(world)]
+            assert shares == [gdist.shard_indices(perm, step, per_rank, r, world, costs) for r in range(world)]
+            chunk = perm[step * g:(step + 1) * g]
+            assert sorted(i for s in shares for i in s) == sorted(chunk)
+            assert all(len(s) == per_rank for s in shares)
+            assert all(s == [i for i in chunk if i in set(s)] for s in shares)          # batch order kept
+            loads = [sum(costs[i] for i in s) for s in shares]
+            blind = [sum(costs[i] for i in chunk[r::world]) for r in range(world)]
+            worst_lpt = max(worst_lpt, max(loads) / min(loads))
+            worst_blind = max(worst_blind, max(blind) / min(blind))
+    assert worst_lpt <= 1.1 < worst_blind
+    # a short last batch: nobody takes more than per_rank, nothing is lost, an empty share is []
+    short = [gdist.shard_indices(perm[:3], 0, 2, r, 4, costs) for r in range(4)]
+    assert sorted(i for s in short for i in s) == sorted(perm[:3]) and [len(s) for s in short].count(0) == 1
+    assert gdist.shard_indices(perm, 0, 6, 0, 1, costs) == perm[:6]                     # one rank: the batch as it is
+    # costs reach a Subset's items through its indices
+    from torch.utils.data import Subset
+
+    from tests.dp_worker import UnequalDataset
+    data = UnequalDataset(6)
+    assert gdist.sample_costs(Subset(Subset(data, [5, 4, 3, 2]), [1, 3])) == [data.items[4][1].n, data.items[2][1].n]
+    assert gdist.sample_costs([1, 2, 3]) is None
+
+
+def _unequal_worker(rank, world, port, n_samples, per_rank, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    gdist.init_from_env(backend="gloo")
+    from model.gnn_model import _ShardedBatches
+    from tests.dp_worker import UnequalDataset
+
+    torch.manual_seed(0)
+    net = torch_ref.ref_init_graph_net("GSpool", HP(20, 4, [16, 16], None, None))
+    gdist.broadcast_parameters(net.parameters())
+    sync = gdist.FlatGradSync(net.parameters())
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    loader = _ShardedBatches(UnequalDataset(n_samples), per_rank, rank, world)
+    assert loader.costs is not None
+    nodes, losses = [], []
+    for item in loader:
+        ids, g, feats, labels = item
+        nodes.append(g.n)
+        sync.zero_grad()
+        sync.weighted_ce_backward(net(_tgraph_of(g), feats), labels, torch.tensor(W), _oracle_ce)
+        losses.append(float(sync.all_reduce_and_normalise()))
+        opt.step()
+    torch.save({"nodes": nodes, "losses": losses}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_epoch_over_unequal_graphs_is_balanced_and_trains_the_same_network(tmp_path):
+    """Two gloo ranks, graphs of 50 - 70 nodes dealt by cost: every step's node counts differ by at most 10 % between
+    the ranks, and the epoch's losses equal the single-process run over the same global batches (same set of graphs per
+    step, hence the same gradient up to summation order)."""
+    from model.gnn_model import _ShardedBatches
+    from tests.dp_worker import UnequalDataset
+
+    world, per_rank, n_samples = 2, 3, 24
+    mp.spawn(_unequal_worker, args=(world, _free_port(), n_samples, per_rank, str(tmp_path)), nprocs=world, join=True)
+    ranks = [torch.load(tmp_path / f"rank{r}.pt", weights_only=False) for r in range(world)]
+    assert ranks[0]["losses"] == ranks[1]["losses"] and len(ranks[0]["nodes"]) == n_samples // (world * per_rank)
+    for a, b in zip(ranks[0]["nodes"], ranks[1]["nodes"]):
+        assert max(a, b) / min(a, b) <= 1.1, (a, b)
+    torch.manual_seed(0)
+    net = torch_ref.ref_init_graph_net("GSpool", HP(20, 4, [16, 16], None, None))
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    losses = []
+    for ids, graph, feats, labels in _ShardedBatches(UnequalDataset(n_samples), world * per_rank, 0, 1):
+        opt.zero_grad()
+        loss = F.cross_entropy(net(_tgraph_of(graph), feats), labels, weight=torch.tensor(W))
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert np.allclose(losses, ranks[0]["losses"], rtol=1e-5, atol=1e-7)
+
+
 # ------------------------------------------------------------------ epoch plumbing of the DP run
 def _tgraph_of(g):
     return torch_ref.TGraph(graph_ref.RefGraph(g.src, g.dst, g.n))

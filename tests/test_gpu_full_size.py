@@ -100,6 +100,47 @@ def test_c3_gat_4x4x256_network_matches_oracle():
     _check_against_oracles(ref, ref64, mine, tg, g, x, y)
 
 
+@pytest.mark.timeout(1500)
+def test_c3_network_on_the_clustered_gat_kernels_matches_oracle():
+    """The path `bench.py --config c3` actually runs: two 15 000-node lattice graphs (30 000 rows, in-degree <= 6) are
+    sent through the CLUSTERED GATConv kernels by the default rules (gts/schedule.py: D = 256, >= 20 000 rows, rows of one
+    8-edge chunk) — forward, source pass and edge pass of all four hidden layers — and the logits, the loss and every
+    gradient are laid beside the fp32 and fp64 oracle, not only beside the plain kernels."""
+    from gts import schedule
+
+    assert (schedule.ENABLED_GAT, schedule.MIN_ROWS_GAT, schedule.MAX_DEGREE_GAT) == (True, 20000, 8), "default rules"
+    hp = HP(4, 4, [256] * 4, [4] * 4, [False] * 4)
+    g, x, y = _lattice_batch(2)
+    assert g.n == 30000 and g.max_in_degree <= 6
+    gd = g.to(DEV)
+    for which in ("gat_in", "gat_edge_in", "gat_out"):
+        assert ops._gat_cluster_schedule(gd, which, g.n, 4, 256) is not None, which
+    calls = []
+    lib = gts._lib.load()
+    real = {name: getattr(lib, name) for name in ("gts_gat_fwd_cluster_f32", "gts_gat_bwd_edge_cluster_f32",
+                                                  "gts_gat_bwd_src_cluster_f32")}
+
+    class Spy:            # counts the clustered launches without changing them
+        def __init__(self, name):
+            self.name = name
+
+        def __call__(self, *args):
+            calls.append(self.name)
+            return real[self.name](*args)
+    tg = torch_ref.TGraph(graph_ref.RefGraph(g.src, g.dst, g.n))
+    ref, ref64, mine = _net_triple("GAT", hp, seed=4)
+    try:
+        for name in real:
+            setattr(lib, name, Spy(name))
+        _check_against_oracles(ref, ref64, mine, tg, g, x, y)
+    finally:
+        for name, fn in real.items():
+            setattr(lib, name, fn)
+    # four hidden layers (H * D = 1024) each way; the one-head classifier layer keeps the plain kernels
+    assert calls.count("gts_gat_fwd_cluster_f32") == 4
+    assert calls.count("gts_gat_bwd_edge_cluster_f32") == 4 and calls.count("gts_gat_bwd_src_cluster_f32") == 4
+
+
 @pytest.mark.timeout(900)
 def test_gat_kernels_full_size_properties_c3():
     """K5-K8 at N_b = 60 000, E_b = 345 400, H = 4, D = 256 (one C3 hidden layer)."""

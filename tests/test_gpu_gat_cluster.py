@@ -97,6 +97,60 @@ def test_clustered_gat_forward_and_source_pass_equal_the_plain_kernels_bit_for_b
             assert torch.equal(a, w), what
 
 
+@pytest.mark.parametrize("name", ["lattice", "lattice_self_loops", "batch"])
+def test_clustered_gatconv_layer_with_bias_and_elu_matches_the_oracle(name):
+    """One GATConv layer (bias + ELU, 4 heads x 256: the C3 hidden layer of /root/reference/model/networks.py:52) on a
+    forced schedule — clustered forward, edge pass and source pass — against oracle/torch_ref.RefGATConv directly
+    (forward rtol 1e-4, gradients rtol 1e-3, as the plain-kernel layer test in tests/test_gpu_model.py)."""
+    import torch.nn.functional as F
+
+    from gts import nn as gnn
+    from oracle import graph_ref, torch_ref
+    from tests.helpers import copy_state
+
+    g = _graphs()[name]
+    for which in ("gat_in", "gat_out"):
+        assert g.cluster_schedule(which) is not None
+    edge_clustered = g.cluster_schedule("gat_edge_in") is not None and g.max_in_degree <= 8
+    assert edge_clustered or name == "batch"
+    tg = torch_ref.TGraph(graph_ref.RefGraph(g.src, g.dst, g.n))
+    torch.manual_seed(len(name))
+    fin, heads, dim = 64, 4, 256
+    ref = torch_ref.RefGATConv(fin, dim, heads, residual=False, activation=F.elu)
+    mine = gnn.GATConv(fin, dim, heads, 0, 0, 0.2, False, F.elu)
+    with torch.no_grad():
+        ref.bias.normal_(0, 0.5)
+    copy_state(mine, ref)
+    mine.to(DEV)
+    x = torch.randn(g.n, fin) * 0.5
+    gout = torch.randn(g.n, heads, dim)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(tg, xr)
+    yr.backward(gout)
+    ran = []
+    lib = _lib.load()
+    real = {k: getattr(lib, k) for k in ("gts_gat_fwd_cluster_f32", "gts_gat_bwd_edge_cluster_f32", "gts_gat_bwd_src_cluster_f32")}
+    try:
+        for k, fn in real.items():
+            setattr(lib, k, (lambda k_, fn_: (lambda *a: (ran.append(k_), fn_(*a))[1]))(k, fn))
+        xd = x.to(DEV).requires_grad_(True)
+        yd = mine(g.to(DEV), xd)
+        yd.backward(gout.to(DEV))
+    finally:
+        for k, fn in real.items():
+            setattr(lib, k, fn)
+    assert "gts_gat_fwd_cluster_f32" in ran and "gts_gat_bwd_src_cluster_f32" in ran
+    assert ("gts_gat_bwd_edge_cluster_f32" in ran) == edge_clustered
+
+    def close(a, b, rtol, atol):
+        a, b = a.detach().cpu(), b.detach()
+        assert torch.allclose(a, b, rtol=rtol, atol=atol), float((a - b).abs().max())
+    close(yd, yr, 1e-4, 1e-5 * max(1.0, float(yr.abs().max())))
+    close(xd.grad, xr.grad, 1e-3, 1e-5 * max(1.0, float(xr.grad.abs().max())))
+    for (pname, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        close(p.grad, q.grad, 1e-3, 2e-5 * max(1.0, float(q.grad.abs().max())))
+
+
 def test_default_rules_pick_the_clustered_kernels_for_the_c3_batch_and_not_for_dense_or_small_graphs(monkeypatch):
     monkeypatch.setattr(schedule, "MIN_ROWS_GAT", 20000)
     monkeypatch.setattr(schedule, "MAX_DEGREE_GAT", 8)

@@ -724,3 +724,41 @@ def test_gat_act_link_stands_down_when_a_dropout_sits_between_the_layers():
         grads.append([p.grad.clone() for p in net.parameters()])
     for a, b in zip(*grads):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", ["unfused_producer", "relu_activation", "no_activation"])
+def test_gat_act_link_is_armed_by_the_producer_only(case):
+    """ActLink is two-sided: the consumer folds ELU' into its input-gradient GEMM only when the producer ran as the
+    fused node WITH ELU (and will therefore skip its own activation backward).  Producers the reference's constructor
+    allows but the fold does not cover — a 50-wide hidden layer (op-by-op path: 50 % 4 != 0, and 4 heads give the fused
+    output layer a 200-wide input at n >= 4096), `activation=F.relu`, `activation=None` (model/networks.py:40-58
+    exposes both arguments) — must give the same gradients with the fold switched on and off, and match autograd of
+    the op-by-op network."""
+    from model.networks import GAT
+    n = 6000
+    src, dst = random_coo(n, 5 * n, seed=6, min_in_degree=1)
+    g = gts.Graph(src, dst, n).to(DEV)
+    torch.manual_seed(1)
+    kwargs = {"unfused_producer": dict(layer_sizes=[50], heads=[4], residuals=[False]),
+              "relu_activation": dict(layer_sizes=[64], heads=[4], residuals=[False], activation=F.relu),
+              "no_activation": dict(layer_sizes=[64], heads=[4], residuals=[False], activation=None)}[case]
+    sizes, heads, res = kwargs.pop("layer_sizes"), kwargs.pop("heads"), kwargs.pop("residuals")
+    net = GAT(4, sizes, 4, heads, res, **kwargs).to(DEV).train()
+    x = torch.from_numpy(synth.node_features(n, 4, 5)).to(DEV)
+    y = torch.from_numpy(synth.node_labels(n, 5)).to(DEV)
+    grads = {}
+    for mode in ("fold", "nofold", "unfused"):
+        saved = gnn.FOLD_GAT_ACT_BWD, gnn.FUSE_GAT_LAYER
+        gnn.FOLD_GAT_ACT_BWD, gnn.FUSE_GAT_LAYER = mode == "fold", mode != "unfused"
+        try:
+            net.zero_grad(set_to_none=True)
+            F.cross_entropy(net(g, x), y).backward()
+        finally:
+            gnn.FOLD_GAT_ACT_BWD, gnn.FUSE_GAT_LAYER = saved
+        grads[mode] = {k: p.grad.clone() for k, p in net.named_parameters()}
+    for name, want in grads["nofold"].items():
+        assert torch.isfinite(grads["fold"][name]).all()
+        assert torch.equal(grads["fold"][name], want), name                  # the link stood down: same launches, same bits
+        ref = grads["unfused"][name]
+        scale = float(ref.abs().max()) + 1e-30
+        assert float((want - ref).abs().max()) <= 2e-4 * scale + 1e-8, name    # and they are the right gradients

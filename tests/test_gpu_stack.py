@@ -112,6 +112,41 @@ def test_gradients_written_into_the_optimizer_flat_buffer_train_the_same_network
         assert torch.equal(states[0][k], states[1][k]), k
 
 
+def test_a_sink_wider_than_the_stack_is_not_used_and_no_gradient_is_lost():
+    """A network with parameters OUTSIDE the fused stack (here a learnable logit scale) under an active GradSink that covers
+    all of them: the stack must hand autograd ordinary per-parameter gradients (the sink stays unfilled), so that the
+    optimizer / FlatGradSync fallback of `p.grad` sees every gradient — none may silently become zero."""
+    g = synth.lattice_graph((9, 8, 7)).to(DEV)
+    torch.manual_seed(3)
+    net = init_graph_net("GSpool", HP(20, 4, [256], None, None)).to(DEV)
+    scale = torch.nn.Parameter(torch.full((4,), 1.5, device=DEV))
+    x = torch.randn(g.n, 20, device=DEV)
+    y = torch.randint(0, 4, (g.n,), device=DEV)
+
+    def grads(sink):
+        net.zero_grad(set_to_none=True)
+        scale.grad = None
+        loss = ops.weighted_cross_entropy(net(g, x) * scale, y, W.to(DEV))
+        if sink is None:
+            loss.backward()
+        else:
+            sink.new_buffer()
+            with gnn.grad_sink(sink):
+                loss.backward()
+        return [p.grad.clone() if p.grad is not None else None for p in (*net.parameters(), scale)]
+
+    want = grads(None)
+    sink = gnn.GradSink([*net.parameters(), scale])
+    got = grads(sink)
+    assert not sink.filled
+    assert all(a is not None and torch.equal(a, b) for a, b in zip(got, want))
+    exact = gnn.GradSink(list(net.parameters()))          # a sink that IS the stack's parameters is filled as before
+    got = grads(exact)
+    assert exact.filled and all(a is None for a in got[:-1]) and torch.equal(got[-1], want[-1])
+    flat = torch.cat([w.reshape(-1) for w in want[:-1]])
+    assert torch.equal(exact.flat[:flat.numel()], flat)
+
+
 def test_stack_entry_points_reject_bad_arguments():
     import ctypes
 
