@@ -82,6 +82,11 @@ struct GemmArgs {
   // over the row blocks in fixed order by sum_chunks)
   int mask_kind;
   float* col_partial;
+  // the same weights in FRAGMENT ORDER (gts_pack_weights_f32; panel kernels only, null = read b / b2 as they are):
+  // bp[seg] for b[seg], bp2 for b2.  One buffer_load_dwordx4 of a 16-row weight fragment then reads 1 KiB of
+  // consecutive bytes (16 accesses of the vector L1) instead of 64 pieces of 16 bytes 1 KiB apart (64 accesses).
+  const float* bp[2];
+  const float* bp2;
 };
 
 // Phase probe of the kernel (start / operands staged / main loop done / tile stored).  The
@@ -603,14 +608,17 @@ constexpr unsigned kOutOfRange = 0x7FFFFFF0u;   // byte offset no operand panel 
 
 // TM + TN 16-byte buffer loads: address = panel base (SGPR resource) + lane offset (one VGPR per
 // fragment row block) + reduction offset (SGPR); offsets past the panel's bytes read as 0
-template <int TM, int TN, bool B_FIRST = false>
+// (`group` = reduction group of 16; the activation panel advances 64 bytes per group, the weights `b_step` bytes: 64 as
+// stored by torch, 1024 in fragment order)
+template <int TM, int TN, bool B_FIRST = false, int B_STEP = 64>
 __device__ __forceinline__ void load_fragments(v4f (&af)[TM], v4f (&bf)[TN], __amdgpu_buffer_rsrc_t ra,
                                                __amdgpu_buffer_rsrc_t rb, const unsigned (&off_a)[TM],
-                                               const unsigned (&off_b)[TN], int k_bytes) {
+                                               const unsigned (&off_b)[TN], int group) {
+  const int k_bytes = 64 * group, kb_bytes = B_STEP * group;
   if constexpr (B_FIRST) {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
-      bf[tn] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rb, off_b[tn], k_bytes, 0));
+      bf[tn] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rb, off_b[tn], kb_bytes, 0));
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
       af[tm] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ra, off_a[tm], k_bytes, 0));
@@ -621,7 +629,7 @@ __device__ __forceinline__ void load_fragments(v4f (&af)[TM], v4f (&bf)[TN], __a
     af[tm] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ra, off_a[tm], k_bytes, 0));
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn)
-    bf[tn] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rb, off_b[tn], k_bytes, 0));
+    bf[tn] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rb, off_b[tn], kb_bytes, 0));
 }
 
 template <int TM, int TN>
@@ -638,6 +646,7 @@ __device__ __forceinline__ void mfma_group(v4acc (&acc)[TM][TN], const v4f (&af)
 struct PanelStage {   // one GEMM of the panel kernel: c[rows of the panel, rb] = act(a0 b0^T + a1 b1^T + bias) (. mask)
   const float* a[2];
   const float* b[2];
+  const float* bp[2];   // b[seg] in fragment order, or null (GemmArgs::bp)
   int lda[2], ldb[2], kseg[2];
   int ra, rb, ldc, relu;
   float* c;
@@ -659,7 +668,7 @@ struct PanelStage {   // one GEMM of the panel kernel: c[rows of the panel, rb] 
 // most of its code (the generic kernel is ~100 KB of instructions, more than the instruction cache).
 enum : int { kEpiBias = 1, kEpiRelu = 2, kEpiMaskBits = 4, kEpiScores = 8, kEpiBitsOut = 16, kEpiEluSums = 32, kEpiRuntime = 256, kEpiAbsent = -1 };
 
-template <int WM, int WN, int DEPTH, int F = kEpiRuntime, int ROWS = kR240, int ILV = 0>
+template <int WM, int WN, int DEPTH, int F = kEpiRuntime, int ROWS = kR240, int ILV = 0, bool PK = false>
 __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int sched, int m0, int n0, int row_end) {
   constexpr bool G = (F & kEpiRuntime) != 0;
   constexpr int WTM = ROWS / WM, WTN = kC240 / WN, TM = WTM / 16, TN = WTN / 16;
@@ -685,24 +694,36 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
     const int cols = min(s.rb - n0, kC240);
     __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(s.a[seg] + static_cast<size_t>(m0) * lda), 0, (row_end - m0) * lda * 4, 0x00020000);
-    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(s.b[seg] + static_cast<size_t>(n0) * ldb), 0, cols * ldb * 4, 0x00020000);
+    // PK: the weights come in fragment order (s.bp): [16-row tile of B][reduction group of 16][lane][4 floats], zero-padded
+    // to whole tiles and groups — a fragment is 1 KiB of consecutive bytes, lane l takes bytes 16 l .. 16 l + 15.  A
+    // compile-time fact of the instantiation (a run-time choice between the two address forms cost 240 spilled registers)
+    constexpr int b_step = PK ? 1024 : 64;
+    const int groups = (kseg + 15) >> 4;
+    __amdgpu_buffer_rsrc_t rb;
     unsigned off_a[TM], off_b[TN];
+    if constexpr (PK) {
+      rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.bp[seg]), 0, ((s.rb + 15) >> 4) * groups * 1024, 0x00020000);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) off_b[tn] = (static_cast<unsigned>((n0 + wn * WTN) / 16 + tn) * groups * 64 + lane) * 16;
+    } else {
+      rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.b[seg] + static_cast<size_t>(n0) * ldb), 0, cols * ldb * 4,
+                                             0x00020000);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) off_b[tn] = (static_cast<unsigned>(wn * WTN + tn * 16 + i16) * ldb + 4 * q) * 4;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) off_a[tm] = (static_cast<unsigned>(wm * WTM + tm * 16 + i16) * lda + 4 * q) * 4;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) off_b[tn] = (static_cast<unsigned>(wn * WTN + tn * 16 + i16) * ldb + 4 * q) * 4;
     const int n_full = kseg / 16, tail = kseg % 16;
     v4f af[R][TM], bf[R][TN];
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u)     // groups 0 .. DEPTH-1 (clamped: re-reads are harmless)
-      if (n_full > 0) load_fragments(af[u], bf[u], ra, rb, off_a, off_b, 64 * min(u, n_full - 1));
+      if (n_full > 0) load_fragments<TM, TN, false, b_step>(af[u], bf[u], ra, rb, off_a, off_b, min(u, n_full - 1));
     int g = 0;
     for (; g + R <= n_full; g += R) {
 #pragma unroll
       for (int u = 0; u < R; ++u) {
-        load_fragments<TM, TN, ILV >= 0>(af[(u + DEPTH) % R], bf[(u + DEPTH) % R], ra, rb, off_a, off_b,
-                                         64 * min(g + u + DEPTH, n_full - 1));
+        load_fragments<TM, TN, ILV >= 0, b_step>(af[(u + DEPTH) % R], bf[(u + DEPTH) % R], ra, rb, off_a, off_b,
+                                                 min(g + u + DEPTH, n_full - 1));
         mfma_group(acc, af[u], bf[u]);
       }
       // pin the software pipeline: the loads of a group are issued before the MFMAs of the group
@@ -730,7 +751,7 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
     for (int u = 0; u < R - 1; ++u) {   // the last n_full % R groups: their fragments are already on the way
       if (g + u < n_full) {
         if (g + u + DEPTH < n_full)
-          load_fragments(af[(u + DEPTH) % R], bf[(u + DEPTH) % R], ra, rb, off_a, off_b, 64 * (g + u + DEPTH));
+          load_fragments<TM, TN, false, b_step>(af[(u + DEPTH) % R], bf[(u + DEPTH) % R], ra, rb, off_a, off_b, g + u + DEPTH);
         mfma_group(acc, af[u], bf[u]);
       }
     }
@@ -741,7 +762,7 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) off_b[tn] = kOutOfRange;
       }
-      load_fragments(af[0], bf[0], ra, rb, off_a, off_b, 64 * n_full);
+      load_fragments<TM, TN, false, b_step>(af[0], bf[0], ra, rb, off_a, off_b, n_full);
       mfma_group(acc, af[0], bf[0]);
     }
   }
@@ -878,7 +899,8 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
   }
 }
 
-template <int WM, int WN, int DEPTH, class Probe = NoProbe, int F1 = kEpiRuntime, int F2 = kEpiRuntime, int ROWS = kR240, int ILV = 0>
+template <int WM, int WN, int DEPTH, class Probe = NoProbe, int F1 = kEpiRuntime, int F2 = kEpiRuntime, int ROWS = kR240, int ILV = 0,
+          bool PK = false>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_kernel(const GemmArgs p) {
   constexpr int WTN = kC240 / WN;
   static_assert((ROWS / WM) % 16 == 0 && WTN % 16 == 0 && WTN % 4 == 0 && (WM * WN) % 4 == 0, "wave tiles are whole 16x16 tiles");
@@ -889,13 +911,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
   Probe::mark(0);
   Probe::mark(1);
   PanelStage s0{};
-  s0.a[0] = p.a[0], s0.a[1] = p.a[1], s0.b[0] = p.b[0], s0.b[1] = p.b[1];
+  s0.a[0] = p.a[0], s0.a[1] = p.a[1], s0.b[0] = p.b[0], s0.b[1] = p.b[1], s0.bp[0] = p.bp[0], s0.bp[1] = p.bp[1];
   s0.lda[0] = p.lda[0], s0.lda[1] = p.lda[1], s0.ldb[0] = p.ldb[0], s0.ldb[1] = p.ldb[1];
   s0.kseg[0] = p.kseg[0], s0.kseg[1] = p.kseg[1];
   s0.ra = p.ra, s0.rb = p.rb, s0.ldc = p.ldc, s0.relu = p.relu, s0.c = p.c, s0.bias = p.bias, s0.mask = p.mask;
   s0.sc_l = p.sc_l, s0.sc_r = p.sc_r, s0.sc_el = p.sc_el, s0.sc_er = p.sc_er;
   s0.bits_out = p.bits_out, s0.bits_in = p.bits_in, s0.mask_kind = p.mask_kind, s0.col_partial = p.col_partial;
-  panel_stage<WM, WN, DEPTH, F1, ROWS, ILV>(s0, lds, p.sched, m0, n0, row_end);
+  panel_stage<WM, WN, DEPTH, F1, ROWS, ILV, PK>(s0, lds, p.sched, m0, n0, row_end);
   Probe::mark(2);
   // With c2 set a second GEMM follows in the same launch: the rows this workgroup has just stored are
   // its A operand (the next layer's fc_pool behind fc_self + fc_neigh; the next input gradient behind
@@ -910,14 +932,23 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_panel_direct_k
     __threadfence_block();
     __syncthreads();                       // ... and so are every other wave's, before any is read back
     PanelStage s1{};
-    s1.a[0] = p.c, s1.a[1] = p.c, s1.b[0] = p.b2, s1.b[1] = p.b2;
+    s1.a[0] = p.c, s1.a[1] = p.c, s1.b[0] = p.b2, s1.b[1] = p.b2, s1.bp[0] = p.bp2, s1.bp[1] = nullptr;
     s1.lda[0] = s1.lda[1] = p.ldc, s1.ldb[0] = s1.ldb[1] = p.ldb2;
     s1.kseg[0] = p.rb, s1.kseg[1] = 0;
     s1.ra = p.ra, s1.rb = p.rb2, s1.ldc = p.ldc2, s1.relu = p.relu2, s1.c = p.c2, s1.bias = p.bias2, s1.mask = nullptr;
-    panel_stage<WM, WN, DEPTH, F2 == kEpiAbsent ? kEpiRuntime : F2, ROWS, ILV>(s1, lds, p.sched, m0, 0, row_end);
+    panel_stage<WM, WN, DEPTH, F2 == kEpiAbsent ? kEpiRuntime : F2, ROWS, ILV, PK>(s1, lds, p.sched, m0, 0, row_end);
   }
   Probe::mark(3);
 }
+
+// the instantiation that reads its weights in fragment order when the call brought a copy of EVERY weight operand
+// (GemmArgs::bp / bp2), else the one that reads them as stored
+#define GTS_PANEL_LAUNCH(F1_, F2_, ILV_)                                                                   \
+  do {                                                                                                    \
+    if (all_packed) gemm_panel_direct_kernel<3, 4, 1, NoProbe, F1_, F2_, ROWS, ILV_, true><<<grid, 768, 0, st>>>(q);   \
+    else gemm_panel_direct_kernel<3, 4, 1, NoProbe, F1_, F2_, ROWS, ILV_, false><<<grid, 768, 0, st>>>(q);             \
+    return launch_status();                                                                               \
+  } while (0)
 
 template <int WM, int WN, int DEPTH, class Probe = NoProbe, int ROWS = kR240>
 int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
@@ -925,6 +956,8 @@ int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
   GemmArgs q = p;
   q.sched = g_gemm_sched;
   if (p.c2 != nullptr) q.sched &= ~2;   // chained launches read their own output back through L1 / L2: ordinary stores only
+  const bool all_packed = p.bp[0] != nullptr && (p.kseg[1] == 0 || p.bp[1] != nullptr) && (p.c2 == nullptr || p.bp2 != nullptr) &&
+                          !(q.sched & 16);   // GTS_OPT_GEMM_SCHED bit 16: ignore the copies (A/B runs)
   if constexpr (WM == 3 && WN == 4 && DEPTH == 1 && std::is_same<Probe, NoProbe>::value) {
     // the launches of the SAGE-pool layer stack at its 256-wide layers: compile-time epilogues
     const bool whole_cols = p.rb % kC240 == 0 && p.ldc % 4 == 0 && (p.mask == nullptr || p.bits_in != nullptr) &&
@@ -933,8 +966,7 @@ int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
     if (p.rb % kC240 == 0 && p.ldc % 4 == 0 && p.mask_kind == 1 && p.mask != nullptr && p.col_partial != nullptr &&
         p.bits_in == nullptr && p.bits_out == nullptr && p.sc_l == nullptr && p.c2 == nullptr && p.bias == nullptr &&
         !p.relu && !(q.sched & 6)) {   // an input gradient through the ELU of the layer below, with that layer's bias gradient
-      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kEpiEluSums, kEpiAbsent, ROWS><<<grid, 768, 0, st>>>(q);
-      return launch_status();
+      GTS_PANEL_LAUNCH(kEpiEluSums, kEpiAbsent, 0);
     }
     const int f1 = (p.bias ? kEpiBias : 0) | (p.relu ? kEpiRelu : 0) | (p.mask ? kEpiMaskBits : 0) | (p.bits_out ? kEpiBitsOut : 0);
     const int f2 = p.c2 == nullptr ? kEpiAbsent : (p.bias2 ? kEpiBias : 0) | (p.relu2 ? kEpiRelu : 0);
@@ -946,8 +978,7 @@ int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
           return launch_status();
         }
       }
-      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kFwd | kEpiBitsOut, kFwd, ROWS><<<grid, 768, 0, st>>>(q);
-      return launch_status();
+      GTS_PANEL_LAUNCH(kFwd | kEpiBitsOut, kFwd, 0);
     }
     if (whole && f1 == kEpiMaskBits && f2 == 0) {                     // a layer's input gradient, then g @ W_neigh below
       if constexpr (ROWS == kR240) {
@@ -956,29 +987,26 @@ int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
           return launch_status();
         }
       }
-      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kEpiMaskBits, 0, ROWS><<<grid, 768, 0, st>>>(q);
-      return launch_status();
+      GTS_PANEL_LAUNCH(kEpiMaskBits, 0, 0);
     }
     if (whole && f1 == kFwd && f2 == kFwd) {                          // the same pair without mask bits (no-grad forward: inference, evaluate)
-      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kFwd, kFwd, ROWS><<<grid, 768, 0, st>>>(q);
-      return launch_status();
+      GTS_PANEL_LAUNCH(kFwd, kFwd, 0);
     }
     if (whole && f1 == kFwd && f2 == kEpiAbsent) {                    // one biased ReLU layer on its own (fc_pool of the first wide layer)
-      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kFwd, kEpiAbsent, ROWS><<<grid, 768, 0, st>>>(q);
-      return launch_status();
+      GTS_PANEL_LAUNCH(kFwd, kEpiAbsent, 0);
     }
     if (whole_cols && p.sc_l != nullptr && f1 == 0 && f2 == kEpiAbsent) {   // GATConv's fc with the attention scores in its epilogue
-      gemm_panel_direct_kernel<3, 4, 1, NoProbe, kEpiScores, kEpiAbsent, ROWS><<<grid, 768, 0, st>>>(q);
-      return launch_status();
+      GTS_PANEL_LAUNCH(kEpiScores, kEpiAbsent, 0);
     }
     if (whole && f1 == 0 && f2 == kEpiAbsent) {                       // a plain product (g @ W_neigh of the top layer)
-      gemm_panel_direct_kernel<3, 4, 1, NoProbe, 0, kEpiAbsent, ROWS><<<grid, 768, 0, st>>>(q);
-      return launch_status();
+      GTS_PANEL_LAUNCH(0, kEpiAbsent, 0);
     }
+    GTS_PANEL_LAUNCH(kEpiRuntime, kEpiRuntime, 0);
   }
   gemm_panel_direct_kernel<WM, WN, DEPTH, Probe, kEpiRuntime, kEpiRuntime, ROWS><<<grid, 64 * WM * WN, 0, st>>>(q);
   return launch_status();
 }
+#undef GTS_PANEL_LAUNCH
 
 // ---- weight gradients, operands straight into MFMA fragments ------------------------------------
 // C[n, k] = sum_m g[m, n] act[m, k] (one split of the node range per blockIdx.z, slabs as above).
@@ -1837,7 +1865,8 @@ int launch_plain(const GemmArgs& p, hipStream_t st) {
       first.c2 = nullptr;
       int rc = launch_plain<true, true>(first, st);
       if (rc != GTS_OK) return rc;
-      next.a[0] = next.a[1] = p.c, next.b[0] = next.b[1] = p.b2;
+      next.a[0] = next.a[1] = p.c, next.b[0] = next.b[1] = p.b2, next.bp[0] = p.bp2;
+      first.bp2 = nullptr;
       next.lda[0] = next.lda[1] = p.ldc, next.ldb[0] = next.ldb[1] = p.ldb2;
       next.kseg[0] = p.rb, next.kseg[1] = 0;
       next.ra = p.ra, next.rb = p.rb2, next.c = p.c2, next.ldc = p.ldc2, next.bias = p.bias2, next.relu = p.relu2;
@@ -1996,7 +2025,7 @@ extern "C" int32_t gts_get_option(int32_t option) {
 extern "C" int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const float* a1,
                                       const float* w1, const float* bias, float* out, int64_t m,
                                       int64_t n, int64_t k0, int64_t k1, int32_t relu,
-                                      uint64_t* relu_bits, void* stream) {
+                                      uint64_t* relu_bits, const float* const* packed, void* stream) {
   using namespace gts;
   if (!a0 || !w0 || !out || ((a1 == nullptr) != (w1 == nullptr))) return GTS_ERR_NULL;
   if (m < 0 || n <= 0 || k0 <= 0 || k1 < 0 || m >= (1LL << 31) || n >= (1 << 20) ||
@@ -2013,6 +2042,7 @@ extern "C" int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const fl
   p.bias = bias, p.relu = relu;
   p.bits_out = reinterpret_cast<unsigned long long*>(relu_bits);
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
+  if (packed != nullptr) p.bp[0] = packed[0], p.bp[1] = a1 ? packed[1] : nullptr;
   return launch_plain<true, true>(p, static_cast<hipStream_t>(stream));
 }
 
@@ -2088,7 +2118,8 @@ extern "C" int32_t gts_linear_fwd_chain_f32(const float* a0, const float* w0, co
                                             const float* w1, const float* bias, float* out,
                                             const float* w2, const float* bias2, float* out2, int64_t m,
                                             int64_t n, int64_t k0, int64_t k1, int32_t relu, int64_t n2,
-                                            int32_t relu2, uint64_t* relu_bits, void* stream) {
+                                            int32_t relu2, uint64_t* relu_bits, const float* const* packed,
+                                            void* stream) {
   using namespace gts;
   if (!a0 || !w0 || !out || !w2 || !out2 || ((a1 == nullptr) != (w1 == nullptr))) return GTS_ERR_NULL;
   if (m < 0 || n <= 0 || n2 <= 0 || k0 <= 0 || k1 < 0 || m >= (1LL << 31) || n >= (1 << 20) || n2 >= (1 << 20) ||
@@ -2107,6 +2138,7 @@ extern "C" int32_t gts_linear_fwd_chain_f32(const float* a0, const float* w0, co
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
   p.b2 = w2, p.bias2 = bias2, p.c2 = out2, p.rb2 = static_cast<int>(n2), p.ldb2 = static_cast<int>(n);
   p.ldc2 = static_cast<int>(n2), p.relu2 = relu2;
+  if (packed != nullptr) p.bp[0] = packed[0], p.bp[1] = a1 ? packed[1] : nullptr, p.bp2 = packed[2];
   return launch_plain<true, true>(p, static_cast<hipStream_t>(stream));
 }
 
@@ -2114,7 +2146,8 @@ extern "C" int32_t gts_linear_bwd_input_chain_t_f32(const float* g0, const float
                                                     const float* w1t, const float* relu_mask,
                                                     const uint64_t* relu_bits, float* gin,
                                                     const float* w2t, float* gin2, int64_t m, int64_t k,
-                                                    int64_t n0, int64_t n1, int64_t k2, void* stream) {
+                                                    int64_t n0, int64_t n1, int64_t k2,
+                                                    const float* const* packed, void* stream) {
   using namespace gts;
   if (!g0 || !w0t || !gin || !w2t || !gin2 || ((g1 == nullptr) != (w1t == nullptr)) || (relu_bits && !relu_mask))
     return GTS_ERR_NULL;
@@ -2132,6 +2165,7 @@ extern "C" int32_t gts_linear_bwd_input_chain_t_f32(const float* g0, const float
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
   p.b2 = w2t, p.bias2 = nullptr, p.c2 = gin2, p.rb2 = static_cast<int>(k2), p.ldb2 = static_cast<int>(k);
   p.ldc2 = static_cast<int>(k2), p.relu2 = 0;
+  if (packed != nullptr) p.bp[0] = packed[0], p.bp[1] = g1 ? packed[1] : nullptr, p.bp2 = packed[2];
   return launch_plain<true, true>(p, static_cast<hipStream_t>(stream));
 }
 
@@ -2163,7 +2197,7 @@ extern "C" int32_t gts_linear_bwd_input_t_f32(const float* g0, const float* w0t,
                                               const float* w1t, const float* relu_mask,
                                               const uint64_t* relu_bits, float* gin,
                                               int64_t m, int64_t k, int64_t n0, int64_t n1,
-                                              void* stream) {
+                                              const float* const* packed, void* stream) {
   using namespace gts;
   if (!g0 || !w0t || !gin || ((g1 == nullptr) != (w1t == nullptr)) || (relu_bits && !relu_mask)) return GTS_ERR_NULL;
   if (m < 0 || k <= 0 || n0 <= 0 || n1 < 0 || m >= (1LL << 31) || k >= (1 << 20) ||
@@ -2179,6 +2213,7 @@ extern "C" int32_t gts_linear_bwd_input_t_f32(const float* g0, const float* w0t,
   p.ra = static_cast<int>(m), p.rb = static_cast<int>(k), p.c = gin, p.ldc = static_cast<int>(k);
   p.mask = relu_mask, p.bits_in = reinterpret_cast<const unsigned long long*>(relu_bits);
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
+  if (packed != nullptr) p.bp[0] = packed[0], p.bp[1] = g1 ? packed[1] : nullptr;
   return launch_plain<true, true>(p, static_cast<hipStream_t>(stream));
 }
 

@@ -31,8 +31,12 @@ inline bool bad_stack(int64_t n_rows, const int64_t* widths, int32_t n_layers) {
 struct FwdPlan {
   int64_t m[kMaxLayers], arg[kMaxLayers], out[kMaxLayers], bits[kMaxLayers];   // byte offsets; -1 = absent
   int64_t p[2];
+  int64_t wp[kMaxLayers][3];   // w_pool / w_self / w_neigh in fragment order (gts_pack_weights_f32); -1 = read as stored
   int64_t total;
 };
+
+// weights the panel GEMMs may read (outputs wider than 128 columns): kept in fragment order beside the activations
+inline bool packs(int64_t out_cols) { return out_cols > 128; }
 
 inline FwdPlan plan_forward(int64_t n, const int64_t* w, int n_layers, bool training, int arg_bytes, int flags) {
   FwdPlan p{};
@@ -49,6 +53,11 @@ inline FwdPlan plan_forward(int64_t n, const int64_t* w, int n_layers, bool trai
   }
   p.p[0] = take(4 * n * widest);
   p.p[1] = take(4 * n * widest);
+  for (int i = 0; i < n_layers; ++i) {
+    p.wp[i][0] = packs(w[i]) ? take(4 * gts_packed_weight_floats(w[i], w[i])) : -1;
+    p.wp[i][1] = packs(w[i + 1]) ? take(4 * gts_packed_weight_floats(w[i + 1], w[i])) : -1;
+    p.wp[i][2] = packs(w[i + 1]) ? take(4 * gts_packed_weight_floats(w[i + 1], w[i])) : -1;
+  }
   p.total = at;
   return p;
 }
@@ -69,6 +78,7 @@ inline bool turns(int64_t rows, int64_t cols) { return cols >= 128 && rows % 4 =
 
 struct BwdPlan {
   int64_t wt[kMaxLayers][3];               // transposed w_pool / w_self / w_neigh (-1 = read as stored)
+  int64_t wtp[kMaxLayers][3];              // the same transposes in fragment order (present whenever wt is)
   int64_t g[kMaxLayers], gp[kMaxLayers];   // g[i] (i >= 1): gradient w.r.t. layer i-1's pre-activation output; gp[i]: w.r.t. fc_pool's
   int64_t gm[2];
   int64_t workspace, workspace_bytes;
@@ -92,6 +102,9 @@ inline BwdPlan plan_backward(int64_t n, const int64_t* w, int n_layers, int flag
     p.wt[i][0] = t && turns(fin, fin) ? take(4 * fin * fin) : -1;
     p.wt[i][1] = t && turns(fout, fin) ? take(4 * fout * fin) : -1;
     p.wt[i][2] = t && turns(fout, fin) ? take(4 * fout * fin) : -1;
+    p.wtp[i][0] = p.wt[i][0] >= 0 ? take(4 * gts_packed_weight_floats(fin, fin)) : -1;       // W^T is [fin, rows of W]
+    p.wtp[i][1] = p.wt[i][1] >= 0 ? take(4 * gts_packed_weight_floats(fin, fout)) : -1;
+    p.wtp[i][2] = p.wt[i][2] >= 0 ? take(4 * gts_packed_weight_floats(fin, fout)) : -1;
     p.g[i] = i > 0 ? take(4 * n * fin) : -1;
     p.gp[i] = take(4 * n * fin);
   }
@@ -154,6 +167,30 @@ extern "C" int32_t gts_sage_pool_stack_fwd_f32(const int32_t* indptr, const int3
   if (n_rows == 0) return GTS_OK;
   char* base = static_cast<char*>(arena);
   auto f32 = [&](int64_t off) { return reinterpret_cast<float*>(base + off); };
+  // the weights the panel GEMMs will read, in fragment order: one launch per weight shape (the weights change once per
+  // optimizer step; 19 matrices of 256 KiB at C2)
+  {
+    struct Batch { int64_t rows, cols; std::vector<const float*> src; std::vector<float*> dst; };
+    std::vector<Batch> batches;
+    for (int i = 0; i < n_layers; ++i) {
+      const int64_t fin = widths[i], fout = widths[i + 1];
+      const int64_t shape[3][2] = {{fin, fin}, {fout, fin}, {fout, fin}};
+      const int which[3] = {0, 2, 3};
+      for (int q = 0; q < 3; ++q) {
+        if (plan.wp[i][q] < 0) continue;
+        Batch* b = nullptr;
+        for (auto& c : batches)
+          if (c.rows == shape[q][0] && c.cols == shape[q][1]) b = &c;
+        if (b == nullptr) batches.push_back({shape[q][0], shape[q][1], {}, {}}), b = &batches.back();
+        b->src.push_back(params[5 * i + which[q]]);
+        b->dst.push_back(f32(plan.wp[i][q]));
+      }
+    }
+    for (const auto& b : batches)
+      GTS_TRY(gts_pack_weights_f32(b.src.data(), b.dst.data(), nullptr, static_cast<int32_t>(b.src.size()), b.rows, b.cols, 0,
+                                   stream));
+  }
+  auto wp = [&](int i, int q) -> const float* { return plan.wp[i][q] >= 0 ? f32(plan.wp[i][q]) : nullptr; };
   const float* h = x;
   float* p = nullptr;   // relu(fc_pool(h)) of the layer about to run, when the previous launch already made it
   int cur = 0;
@@ -167,7 +204,8 @@ extern "C" int32_t gts_sage_pool_stack_fwd_f32(const int32_t* indptr, const int3
     const bool last = i == n_layers - 1;
     if (p == nullptr) {
       p = f32(plan.p[cur]);
-      GTS_TRY(gts_linear_fwd_f32(h, w_pool, nullptr, nullptr, b_pool, p, n_rows, fin, fin, 0, 1, nullptr, stream));
+      const float* packed[2] = {wp(i, 0), nullptr};
+      GTS_TRY(gts_linear_fwd_f32(h, w_pool, nullptr, nullptr, b_pool, p, n_rows, fin, fin, 0, 1, nullptr, packed, stream));
     }
     float* m = f32(plan.m[i]);
     void* arg = train ? static_cast<void*>(base + plan.arg[i]) : nullptr;
@@ -183,11 +221,13 @@ extern "C" int32_t gts_sage_pool_stack_fwd_f32(const int32_t* indptr, const int3
     if ((flags & kFlagChain) && !last && chainable(fout, fin, fin, fout)) {
       // fc_self + fc_neigh of this layer and fc_pool of the next one in one launch
       float* p_next = f32(plan.p[cur ^ 1]);
+      const float* packed[3] = {wp(i, 1), wp(i, 2), wp(i + 1, 0)};
       GTS_TRY(gts_linear_fwd_chain_f32(h, w_self, m, w_neigh, bias, out, params[5 * (i + 1)], params[5 * (i + 1) + 1], p_next,
-                                       n_rows, fout, fin, fin, 1, fout, 1, bits, stream));
+                                       n_rows, fout, fin, fin, 1, fout, 1, bits, packed, stream));
       p = p_next, cur ^= 1;
     } else {
-      GTS_TRY(gts_linear_fwd_f32(h, w_self, m, w_neigh, bias, out, n_rows, fout, fin, fin, last ? 0 : 1, bits, stream));
+      const float* packed[2] = {wp(i, 1), wp(i, 2)};
+      GTS_TRY(gts_linear_fwd_f32(h, w_self, m, w_neigh, bias, out, n_rows, fout, fin, fin, last ? 0 : 1, bits, packed, stream));
       p = nullptr;
     }
     h = out;
@@ -233,7 +273,7 @@ extern "C" int32_t gts_sage_pool_stack_bwd_f32(const int32_t* t_indptr, const in
 
   // transposed weights: one batch per shape, in the order the shapes first appear (pool, self, neigh per layer)
   {
-    struct Batch { int64_t rows, cols; std::vector<const float*> src; std::vector<float*> dst; };
+    struct Batch { int64_t rows, cols; std::vector<const float*> src; std::vector<float*> dst, packed; };
     std::vector<Batch> batches;
     for (int i = 0; i < n_layers; ++i) {
       const int64_t fin = widths[i], fout = widths[i + 1];
@@ -244,23 +284,29 @@ extern "C" int32_t gts_sage_pool_stack_bwd_f32(const int32_t* t_indptr, const in
         Batch* b = nullptr;
         for (auto& c : batches)
           if (c.rows == shape[q][0] && c.cols == shape[q][1]) b = &c;
-        if (b == nullptr) batches.push_back({shape[q][0], shape[q][1], {}, {}}), b = &batches.back();
+        if (b == nullptr) batches.push_back({shape[q][0], shape[q][1], {}, {}, {}}), b = &batches.back();
         b->src.push_back(params[5 * i + which[q]]);
         b->dst.push_back(f32(plan.wt[i][q]));
+        b->packed.push_back(f32(plan.wtp[i][q]));
       }
     }
+    // W^T twice in one launch per shape: row-major (the tiles that stage through LDS) and in fragment order (the panel kernels)
     for (const auto& b : batches)
-      GTS_TRY(gts_transpose_batch_f32(b.src.data(), b.dst.data(), static_cast<int32_t>(b.src.size()), b.rows, b.cols, stream));
+      GTS_TRY(gts_pack_weights_f32(b.src.data(), b.packed.data(), b.dst.data(), static_cast<int32_t>(b.src.size()), b.rows,
+                                   b.cols, 1, stream));
   }
   auto wt = [&](int i, int q) -> const float* { return plan.wt[i][q] >= 0 ? f32(plan.wt[i][q]) : nullptr; };
+  auto wtp = [&](int i, int q) -> const float* { return plan.wtp[i][q] >= 0 ? f32(plan.wtp[i][q]) : nullptr; };
 
   // input gradient g0 @ w0 [+ g1 @ w1] into `gin` [n_rows, k]: transposed weights when every operand has them
   auto igrad = [&](const float* g0, const float* w0, const float* w0t, int64_t n0, const float* g1, const float* w1,
                    const float* w1t, int64_t n1, const float* relu_mask, const uint64_t* relu_bits, float* gin,
-                   int64_t k) -> int32_t {
-    if (w0t != nullptr && (g1 == nullptr || w1t != nullptr))
+                   int64_t k, const float* w0tp, const float* w1tp) -> int32_t {
+    if (w0t != nullptr && (g1 == nullptr || w1t != nullptr)) {
+      const float* packed[2] = {w0tp, g1 ? w1tp : nullptr};
       return gts_linear_bwd_input_t_f32(g0, w0t, g1, g1 ? w1t : nullptr, relu_mask, relu_mask ? relu_bits : nullptr, gin,
-                                        n_rows, k, n0, g1 ? n1 : 0, stream);
+                                        n_rows, k, n0, g1 ? n1 : 0, packed, stream);
+    }
     return gts_linear_bwd_input_f32(g0, w0, g1, g1 ? w1 : nullptr, relu_mask, gin, n_rows, k, n0, g1 ? n1 : 0, stream);
   };
 
@@ -286,7 +332,7 @@ extern "C" int32_t gts_sage_pool_stack_bwd_f32(const int32_t* t_indptr, const in
     const void* arg = acts + fwd.arg[i];
     if (gm == nullptr) {
       float* buf = f32(plan.gm[cur]);
-      GTS_TRY(igrad(g, w_neigh, wt(i, 2), fout, nullptr, nullptr, nullptr, 0, nullptr, nullptr, buf, fin));
+      GTS_TRY(igrad(g, w_neigh, wt(i, 2), fout, nullptr, nullptr, nullptr, 0, nullptr, nullptr, buf, fin, wtp(i, 2), nullptr));
       gm = buf;
     }
     float* gp = f32(plan.gp[i]);   // ReLU'(p) is already in the winner record
@@ -308,15 +354,16 @@ extern "C" int32_t gts_sage_pool_stack_bwd_f32(const int32_t* t_indptr, const in
       if ((flags & kFlagChain) && wt(i, 1) && wt(i, 0) && below_t && chainable(fin, fout, fin, below_in)) {
         // this layer's input gradient and the next one's g @ W_neigh in one launch
         float* gm_next = f32(plan.gm[cur ^ 1]);
+        const float* packed[3] = {wtp(i, 1), wtp(i, 0), wtp(i - 1, 2)};
         GTS_TRY(gts_linear_bwd_input_chain_t_f32(g, wt(i, 1), gp, wt(i, 0), h, hbits, g_next, below_t, gm_next, n_rows, fin,
-                                                 fout, fin, below_in, stream));
+                                                 fout, fin, below_in, packed, stream));
         gm = gm_next, cur ^= 1;
       } else {
-        GTS_TRY(igrad(g, w_self, wt(i, 1), fout, gp, w_pool, wt(i, 0), fin, h, hbits, g_next, fin));
+        GTS_TRY(igrad(g, w_self, wt(i, 1), fout, gp, w_pool, wt(i, 0), fin, h, hbits, g_next, fin, wtp(i, 1), wtp(i, 0)));
       }
       g = g_next;
     } else if (gx != nullptr) {
-      GTS_TRY(igrad(g, w_self, wt(i, 1), fout, gp, w_pool, wt(i, 0), fin, nullptr, nullptr, gx, fin));
+      GTS_TRY(igrad(g, w_self, wt(i, 1), fout, gp, w_pool, wt(i, 0), fin, nullptr, nullptr, gx, fin, wtp(i, 1), wtp(i, 0)));
     }
   }
   for (const auto& grp : groups) {

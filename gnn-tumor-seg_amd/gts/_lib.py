@@ -10,7 +10,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgts_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "gts_hip.h")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -53,18 +53,20 @@ SIGNATURES = {
     "gts_adamw_f32": [_p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _i64, _p],
     "gts_label_confusion_workspace": [_i64],
     "gts_label_confusion_i16": [_p, _p, _p, _p, _i64, _i64, _p],
-    "gts_linear_fwd_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p, _p],
+    "gts_linear_fwd_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p, _p, _p],
     "gts_relu_bits_bytes": [_i64, _i64],
     "gts_relu_bits_pay": [_i64, _i64],
     "gts_linear_bwd_input_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
-    "gts_linear_bwd_input_t_f32": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
+    "gts_linear_bwd_input_t_f32": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p],
     "gts_linear_bwd_input_t_act_workspace": [_i64, _i64],
     "gts_linear_bwd_input_t_act_f32": [_p, _p, _p, _p, _p, _i32, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "gts_transpose_batch_f32": [_p, _p, _i32, _i64, _i64, _p],
+    "gts_packed_weight_floats": [_i64, _i64],
+    "gts_pack_weights_f32": [_p, _p, _p, _i32, _i64, _i64, _i32, _p],
     "gts_gat_fc_scores_workspace": [_i64, _i64, _i64],
     "gts_gat_fc_scores_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
-    "gts_linear_fwd_chain_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _i64, _i32, _p, _p],
-    "gts_linear_bwd_input_chain_t_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "gts_linear_fwd_chain_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _i64, _i32, _p, _p, _p],
+    "gts_linear_bwd_input_chain_t_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p],
     "gts_linear_bwd_weight_workspace": [_i64, _i64, _i64, _i32],
     "gts_linear_bwd_weight_f32": [_p, _p, _p, _p, _i32, _p, _i64, _i64, _i64, _i64, _p],
     "gts_sage_pool_stack_fwd_arena": [_i64, _p, _i32, _i32, _i32, _i32, _p],
@@ -83,7 +85,8 @@ _RESTYPE = {"gts_error_string": ctypes.c_char_p, "gts_linear_bwd_weight_workspac
             "gts_weighted_ce_workspace": _i64, "gts_gat_reduce_workspace": _i64,
             "gts_label_confusion_workspace": _i64, "gts_gat_fc_scores_workspace": _i64,
             "gts_relu_bits_bytes": _i64, "gts_cluster_record_words": _i64, "gts_sage_pool_stack_fwd_arena": _i64, "gts_sage_pool_stack_bwd_scratch": _i64, "gts_cluster_lds_bytes": _i64,
-            "gts_linear_bwd_input_t_act_workspace": _i64, "gts_gat_cluster_workspace": _i64}
+            "gts_linear_bwd_input_t_act_workspace": _i64, "gts_gat_cluster_workspace": _i64,
+            "gts_packed_weight_floats": _i64}
 
 COLLATE_MAX_SCHEDULES = 6      # GTS_COLLATE_MAX_SCHEDULES
 

@@ -129,9 +129,57 @@ def unpack_relu_bits(bits, m, n):
     return on.reshape(-1, n)[:m]
 
 
-def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False, relu_bits=None):
+def _packed_array(packed, weights):
+    """ctypes pointer table for the `packed` argument of the GEMM entry points: one entry per weight operand (None
+    where there is no fragment-order copy), or None when there is none at all.  A copy must come from pack_weights of
+    the operand it stands beside (size checked here; the bytes are the caller's business)."""
+    import ctypes
+
+    if packed is None or all(q is None for q in packed):
+        return None
+    if len(packed) != len(weights):
+        raise _lib.GtsError(f"packed= takes one entry per weight operand ({len(weights)}), got {len(packed)}")
+    for q, w in zip(packed, weights):
+        if q is None:
+            continue
+        if w is None:
+            raise _lib.GtsError("a fragment-order copy was passed for a weight operand that is absent")
+        want = _lib.load().gts_packed_weight_floats(w.shape[0], w.shape[1])
+        if q.dtype != torch.float32 or not q.is_contiguous() or q.numel() != want or q.device != w.device:
+            raise _lib.GtsError(f"shapes do not match: fragment-order copy of a {tuple(w.shape)} operand holds {want} floats")
+    return (ctypes.c_void_p * len(packed))(*[ptr(q) for q in packed])
+
+
+def pack_weights(mats, transposed=False, want_plain=False):
+    """Fragment-order copies of same-shape weight matrices for the panel GEMMs (gts_pack_weights_f32; layout in
+    include/gts_hip.h): [w [R, C], ...] -> [packed(w), ...], or with transposed=True [packed(w^T), ...] — and, with
+    want_plain, also [w^T row-major, ...] from the same launch (what transpose_batch returns).  One launch per 32."""
+    import ctypes
+
+    if not mats:
+        return ([], []) if want_plain else []
+    rows, cols = mats[0].shape
+    mats = [m.contiguous() for m in mats]
+    dev = _chk(*mats)
+    for m in mats:
+        _same(tuple(m.shape), (rows, cols), "matrices of one pack batch")
+    lib = _lib.load()
+    n, k = (cols, rows) if transposed else (rows, cols)
+    each = lib.gts_packed_weight_floats(n, k)
+    out = torch.empty((len(mats), each), dtype=torch.float32, device=dev)
+    plain = torch.empty((len(mats), cols, rows), dtype=torch.float32, device=dev) if (want_plain and transposed) else None
+    arr = ctypes.c_void_p * len(mats)
+    check(lib.gts_pack_weights_f32(arr(*[ptr(m) for m in mats]), arr(*[ptr(out[q]) for q in range(len(mats))]),
+                                   arr(*[ptr(plain[q]) for q in range(len(mats))]) if plain is not None else None,
+                                   len(mats), rows, cols, 1 if transposed else 0, current_stream()), "gts_pack_weights_f32")
+    packed = list(out.unbind(0))
+    return (list(plain.unbind(0)), packed) if plain is not None else packed
+
+
+def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False, relu_bits=None, packed=None):
     """out = act(a0 @ w0^T [+ a1 @ w1^T] + bias).  a [M,K], w [N,K] (torch Linear layout).
-    relu_bits (from relu_bits_empty): also filled with out > 0, one bit per element."""
+    relu_bits (from relu_bits_empty): also filled with out > 0, one bit per element.
+    packed: (pack_weights copy of w0, of w1) or None entries — read by the panel kernels instead of w (same values)."""
     _same(_mat(a0, "a0").shape[1], _mat(w0, "w0").shape[1], "inner dims of a0 @ w0^T")
     if (a1 is None) != (w1 is None):
         raise _lib.GtsError("a1 and w1 go together")
@@ -150,22 +198,23 @@ def linear_fwd(a0, w0, a1=None, w1=None, bias=None, relu=False, relu_bits=None):
     out = torch.empty((m, n), dtype=torch.float32, device=dev)
     k0, k1 = a0.shape[1], a1.shape[1] if a1 is not None else 0
     bias = bias.contiguous() if bias is not None else None
+    table = _packed_array(packed, (w0, w1))
 
     def launch():
         check(_lib.load().gts_linear_fwd_f32(ptr(a0), ptr(w0), ptr(a1), ptr(w1), ptr(bias), ptr(out),
-                                             m, n, k0, k1, 1 if relu else 0, ptr(relu_bits), current_stream()),
+                                             m, n, k0, k1, 1 if relu else 0, ptr(relu_bits), table, current_stream()),
               "gts_linear_fwd_f32")
 
     _timed("fwd", 2.0 * m * n * (k0 + k1), launch)
     return out
 
 
-def linear_fwd_chain(a0, w0, a1, w1, bias, relu, w2, bias2, relu2, relu_bits=None):
+def linear_fwd_chain(a0, w0, a1, w1, bias, relu, w2, bias2, relu2, relu_bits=None, packed=None):
     """(out, out2) with out = act(a0 @ w0^T [+ a1 @ w1^T] + bias) and out2 = act2(out @ w2^T + bias2): the two
     GEMMs of consecutive layers in ONE launch when the operands are tall and at most 256 wide (the workgroup
     that has produced a row panel of `out` multiplies it on), otherwise two launches — same values either way.
     All widths must be multiples of 4 (no padding here: callers fall back to two linear_fwd calls).
-    relu_bits: filled with out > 0 (as in linear_fwd)."""
+    relu_bits: filled with out > 0 (as in linear_fwd).  packed: (copy of w0, of w1, of w2) from pack_weights, or None."""
     _same(_mat(a0, "a0").shape[1], _mat(w0, "w0").shape[1], "inner dims of a0 @ w0^T")
     if (a1 is None) != (w1 is None):
         raise _lib.GtsError("a1 and w1 go together")
@@ -187,15 +236,16 @@ def linear_fwd_chain(a0, w0, a1, w1, bias, relu, w2, bias2, relu2, relu_bits=Non
     _chk_bits(relu_bits, m, n, "relu_bits")
     out = torch.empty((m, n), dtype=torch.float32, device=dev)
     out2 = torch.empty((m, n2), dtype=torch.float32, device=dev)
+    table = _packed_array(packed, (w0, w1, w2))
     _timed("fwd", 2.0 * m * n * (k0 + k1) + 2.0 * m * n2 * n, lambda: check(
         _lib.load().gts_linear_fwd_chain_f32(ptr(a0), ptr(w0), ptr(a1), ptr(w1), ptr(bias), ptr(out), ptr(w2),
                                              ptr(bias2), ptr(out2), m, n, k0, k1, 1 if relu else 0, n2,
-                                             1 if relu2 else 0, ptr(relu_bits), current_stream()),
+                                             1 if relu2 else 0, ptr(relu_bits), table, current_stream()),
         "gts_linear_fwd_chain_f32"))
     return out, out2
 
 
-def linear_bwd_input_chain_t(g0, w0t, g1, w1t, relu_mask, w2t, relu_bits=None):
+def linear_bwd_input_chain_t(g0, w0t, g1, w1t, relu_mask, w2t, relu_bits=None, packed=None):
     """(gin, gin2) with gin = (g0 @ w0 [+ g1 @ w1]) (zeroed where relu_mask <= 0) and gin2 = gin @ w2, from
     TRANSPOSED weights (w0t [K,N0], w1t [K,N1], w2t [K2,K]); one launch under the conditions of linear_fwd_chain.
     relu_bits: relu_mask > 0 as bits (from the forward call that made relu_mask) — read instead of its floats."""
@@ -219,10 +269,11 @@ def linear_bwd_input_chain_t(g0, w0t, g1, w1t, relu_mask, w2t, relu_bits=None):
     relu_bits = relu_bits if relu_mask is not None else None
     gin = torch.empty((m, k), dtype=torch.float32, device=dev)
     gin2 = torch.empty((m, k2), dtype=torch.float32, device=dev)
+    table = _packed_array(packed, (w0t, w1t, w2t))
     _timed("igrad", 2.0 * m * k * (n0 + n1) + 2.0 * m * k2 * k, lambda: check(
         _lib.load().gts_linear_bwd_input_chain_t_f32(ptr(g0), ptr(w0t), ptr(g1), ptr(w1t), ptr(relu_mask),
                                                      ptr(relu_bits), ptr(gin), ptr(w2t), ptr(gin2), m, k, n0, n1, k2,
-                                                     current_stream()),
+                                                     table, current_stream()),
         "gts_linear_bwd_input_chain_t_f32"))
     return gin, gin2
 
@@ -273,7 +324,7 @@ def transpose_batch(mats):
     return list(out.unbind(0))
 
 
-def linear_bwd_input_t(g0, w0t, g1=None, w1t=None, relu_mask=None, relu_bits=None):
+def linear_bwd_input_t(g0, w0t, g1=None, w1t=None, relu_mask=None, relu_bits=None, packed=None):
     """linear_bwd_input from TRANSPOSED weights (w0t [K,N0] = w0.t(), from transpose_batch): the
     GEMM then runs in the forward kernel's form.  Same values, bit for bit.  All widths % 4 == 0.
     relu_bits: relu_mask > 0 as bits (see linear_fwd) — read instead of the floats where the kernel can."""
@@ -295,9 +346,10 @@ def linear_bwd_input_t(g0, w0t, g1=None, w1t=None, relu_mask=None, relu_bits=Non
     relu_bits = relu_bits if relu_mask is not None else None
     _chk_bits(relu_bits, m, k, "relu_bits")
     gin = torch.empty((m, k), dtype=torch.float32, device=dev)
+    table = _packed_array(packed, (w0t, w1t))
     _timed("igrad", 2.0 * m * k * (n0 + n1), lambda: check(
         _lib.load().gts_linear_bwd_input_t_f32(ptr(g0), ptr(w0t), ptr(g1), ptr(w1t), ptr(relu_mask), ptr(relu_bits),
-                                               ptr(gin), m, k, n0, n1, current_stream()), "gts_linear_bwd_input_t_f32"))
+                                               ptr(gin), m, k, n0, n1, table, current_stream()), "gts_linear_bwd_input_t_f32"))
     return gin
 
 

@@ -183,6 +183,17 @@ def _pool_layer_weight_grads(g, gp, h, m, w_pool, w_self):
     return g_ws, g_wn, g_wp, g_bias, g_bp
 
 
+def _pack_by_shape(weights, transposed):
+    """{id(w): fragment-order copy} of `weights`, one gts_pack_weights_f32 launch per weight shape."""
+    by_shape, out = {}, {}
+    for w in weights:
+        by_shape.setdefault(tuple(w.shape), []).append(w)
+    for ws in by_shape.values():
+        for w, wp in zip(ws, dense.pack_weights(ws, transposed=transposed)):
+            out[id(w)] = wp
+    return out
+
+
 class _SagePoolStack(torch.autograd.Function):
     """A whole stack of SAGEConv('pool') layers (ReLU on all but the last) as ONE autograd node.
 
@@ -198,11 +209,15 @@ class _SagePoolStack(torch.autograd.Function):
         saved = []
         hbits = None                      # h > 0 as bits (h is a ReLU output from layer 1 on): the backward's mask
         p = None                          # relu(fc_pool(h)) of the layer about to run, when already computed
+        # the weights the panel GEMMs may read (outputs wider than 128 columns), in fragment order: one launch per shape,
+        # as gts_sage_pool_stack_fwd_f32 does (csrc/gts_stack.hip)
+        fragment = _pack_by_shape([w for i in range(n_layers) for w in (params[5 * i], params[5 * i + 2], params[5 * i + 3])
+                                   if w.shape[0] > 128 and w.shape[1] % 4 == 0], transposed=False)
         for i in range(n_layers):
             w_pool, b_pool, w_self, w_neigh, bias = params[5 * i:5 * i + 5]
             last = i == n_layers - 1
             if p is None:
-                p = dense.linear_fwd(h, w_pool, bias=b_pool, relu=True)
+                p = dense.linear_fwd(h, w_pool, bias=b_pool, relu=True, packed=(fragment.get(id(w_pool)), None))
             m, arg = ops.spmm_max_fwd(g, p, want_arg=need_bwd, relu_input=True)   # p is not kept
             p = None
             nxt = params[5 * (i + 1):5 * (i + 1) + 2] if not last else None
@@ -210,9 +225,11 @@ class _SagePoolStack(torch.autograd.Function):
                 if RELU_MASK_BITS and need_bwd and not last and dense.relu_bits_pay(h.shape[0], w_self.shape[0]) else None
             if CHAIN_LAYER_GEMMS and nxt is not None and _chainable(h, w_self, m, nxt[0]):
                 # fc_self + fc_neigh of this layer and fc_pool of the next one in one launch
-                out, p = dense.linear_fwd_chain(h, w_self, m, w_neigh, bias, True, nxt[0], nxt[1], True, relu_bits=obits)
+                out, p = dense.linear_fwd_chain(h, w_self, m, w_neigh, bias, True, nxt[0], nxt[1], True, relu_bits=obits,
+                                                packed=(fragment.get(id(w_self)), fragment.get(id(w_neigh)), fragment.get(id(nxt[0]))))
             else:
-                out = dense.linear_fwd(h, w_self, m, w_neigh, bias=bias, relu=not last, relu_bits=obits)
+                out = dense.linear_fwd(h, w_self, m, w_neigh, bias=bias, relu=not last, relu_bits=obits,
+                                       packed=(fragment.get(id(w_self)), fragment.get(id(w_neigh))))
             saved += [h, m, arg, hbits]
             h, hbits = out, obits
         if need_bwd:
@@ -242,20 +259,22 @@ class _SagePoolStack(torch.autograd.Function):
         # Input gradients run in the forward GEMM's form on transposed weights (one batched
         # transpose per weight shape and backward pass; wide outputs only — the 4-wide first /
         # last layers keep the strided-operand kernel).
-        turned = {}
+        turned, turned_fragment = {}, {}      # W^T row-major / in fragment order (the panel kernels), one launch per shape
         if TRANSPOSED_IGRAD:
             by_shape = {}
             for w in (params[5 * i + j] for i in range(n) for j in (0, 2, 3)):
                 if w.shape[1] >= 128 and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0:
                     by_shape.setdefault(tuple(w.shape), []).append(w)
             for ws in by_shape.values():
-                for w, wt in zip(ws, dense.transpose_batch(ws)):
-                    turned[id(w)] = wt
+                plain, packed = dense.pack_weights(ws, transposed=True, want_plain=True)
+                for w, wt, wp in zip(ws, plain, packed):
+                    turned[id(w)], turned_fragment[id(w)] = wt, wp
 
         def igrad(g0, w0, g1=None, w1=None, relu_mask=None, relu_bits=None):
             if id(w0) in turned and (w1 is None or id(w1) in turned) and g0.is_contiguous():
                 return dense.linear_bwd_input_t(g0, turned[id(w0)], g1, turned[id(w1)] if w1 is not None else None,
-                                                relu_mask=relu_mask, relu_bits=relu_bits)
+                                                relu_mask=relu_mask, relu_bits=relu_bits,
+                                                packed=(turned_fragment[id(w0)], turned_fragment[id(w1)] if w1 is not None else None))
             return dense.linear_bwd_input(g0, w0, g1, w1, relu_mask=relu_mask)
 
         def defer(grad_out, act, slot, bias_slot):
@@ -288,7 +307,9 @@ class _SagePoolStack(torch.autograd.Function):
                         and _chainable(g, w_self.t(), gp, below.t()):
                     # this layer's input gradient and the next one's g @ W_neigh in one launch
                     g, gm = dense.linear_bwd_input_chain_t(g, turned[id(w_self)], gp, turned[id(w_pool)], h,
-                                                           turned[id(below)], relu_bits=hbits)
+                                                           turned[id(below)], relu_bits=hbits,
+                                                           packed=(turned_fragment[id(w_self)], turned_fragment[id(w_pool)],
+                                                                   turned_fragment[id(below)]))
                 else:
                     g = igrad(g, w_self, gp, w_pool, relu_mask=h, relu_bits=hbits)
             elif ctx.needs_input_grad[1]:

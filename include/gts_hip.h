@@ -292,7 +292,26 @@ int64_t gts_relu_bits_bytes(int64_t m, int64_t n);
 int32_t gts_relu_bits_pay(int64_t m, int64_t n);
 int32_t gts_linear_fwd_f32(const float* a0, const float* w0, const float* a1, const float* w1,
                            const float* bias, float* out, int64_t m, int64_t n, int64_t k0,
-                           int64_t k1, int32_t relu, uint64_t* relu_bits, void* stream);
+                           int64_t k1, int32_t relu, uint64_t* relu_bits, const float* const* packed,
+                           void* stream);
+/* Weights in FRAGMENT ORDER — the optional `packed` argument of gts_linear_fwd_f32, gts_linear_fwd_chain_f32,
+ * gts_linear_bwd_input_t_f32 and gts_linear_bwd_input_chain_t_f32: a HOST array with one device pointer per weight
+ * operand of the call, in argument order (w0, w1[, w2] resp. w0t, w1t[, w2t]; NULL entries and a NULL array are
+ * allowed), each a copy of that operand made by gts_pack_weights_f32.  The nn.Linear weights inside SAGEConv
+ * (model/networks.py:25-30) are read by every workgroup of a layer GEMM; as torch stores them ([out, in] row-major) a
+ * wave's 16-row MFMA fragment is 64 pieces of 16 bytes 1 KiB apart — 64 accesses of the vector L1, whose access rate
+ * bounds the tall panel kernels (profiles/r04/panel144_l1_bound.log) — in fragment order it is 1 KiB of consecutive
+ * bytes (16 accesses).  Same values, same reduction order: results are bit-identical with and without the copies;
+ * kernels other than the panel kernels ignore them and read the plain operand.
+ *   B [n, k] = the operand as the GEMM reads it (rows = output columns, columns = reduction); G = ceil(k / 16):
+ *   packed[((T * G + g) * 64 + lane) * 4 + e] = B[16 T + (lane & 15)][16 g + 4 (lane >> 4) + e], 0 past the edges;
+ *   gts_packed_weight_floats(n, k) = ceil(n / 16) * G * 256 floats.
+ * gts_pack_weights_f32: n_mats matrices src[q] [rows, cols] of one shape (HOST arrays of device pointers), one launch
+ * per 32.  transposed = 0: B = src[q];  transposed = 1: B = src[q]^T (the input gradient's operand), and plain_t
+ * (optional, only then) also receives src[q]^T row-major [cols, rows] — what gts_transpose_batch_f32 writes. */
+int64_t gts_packed_weight_floats(int64_t n, int64_t k);
+int32_t gts_pack_weights_f32(const float* const* src, float* const* dst, float* const* plain_t, int32_t n_mats,
+                             int64_t rows, int64_t cols, int32_t transposed, void* stream);
 /* input gradient:  gin[m, k] = sum_n g0[m,n] w0[n,k] + (g1 ? sum_n g1[m,n] w1[n,k] : 0)
  *   g0 [M,N0], w0 [N0,K], g1 [M,N1], w1 [N1,K].  relu_mask (optional, [M,K]): gin is zeroed
  *   where relu_mask <= 0, i.e. the ReLU backward of the layer that produced this input. */
@@ -307,7 +326,7 @@ int32_t gts_linear_bwd_input_f32(const float* g0, const float* w0, const float* 
  * its floats as before — the result is the same either way. */
 int32_t gts_linear_bwd_input_t_f32(const float* g0, const float* w0t, const float* g1, const float* w1t,
                                    const float* relu_mask, const uint64_t* relu_bits, float* gin, int64_t m,
-                                   int64_t k, int64_t n0, int64_t n1, void* stream);
+                                   int64_t k, int64_t n0, int64_t n1, const float* const* packed, void* stream);
 /* the same input gradient carried through the activation of the layer BELOW (a GATConv stack: the next layer's input IS the
  * ELU output of this one, model/networks.py:46-58,61-63), with that layer's bias gradient:
  *   gin[m, k] = (g0 w0 (+ g1 w1)) * act'(act_out),  act' through the activation's OUTPUT act_out [m, k]: activation 1 = ELU
@@ -339,11 +358,13 @@ int32_t gts_gat_fc_scores_f32(const float* h, const float* w_fc, const float* at
 int32_t gts_linear_fwd_chain_f32(const float* a0, const float* w0, const float* a1, const float* w1,
                                  const float* bias, float* out, const float* w2, const float* bias2,
                                  float* out2, int64_t m, int64_t n, int64_t k0, int64_t k1, int32_t relu,
-                                 int64_t n2, int32_t relu2, uint64_t* relu_bits, void* stream);
+                                 int64_t n2, int32_t relu2, uint64_t* relu_bits, const float* const* packed,
+                                 void* stream);
 int32_t gts_linear_bwd_input_chain_t_f32(const float* g0, const float* w0t, const float* g1,
                                          const float* w1t, const float* relu_mask, const uint64_t* relu_bits,
                                          float* gin, const float* w2t, float* gin2, int64_t m, int64_t k,
-                                         int64_t n0, int64_t n1, int64_t k2, void* stream);
+                                         int64_t n0, int64_t n1, int64_t k2, const float* const* packed,
+                                         void* stream);
 /* dst[q][c, r] = src[q][r, c] for n_mats matrices of one shape [rows, cols] in one launch per 32
  * (src, dst: HOST arrays of device pointers).  Serves the transposed-weight form above: the
  * weights of a layer stack (torch Linear layout [out, in]) are turned once per backward pass. */

@@ -143,7 +143,7 @@ def test_rows240_narrow_output_through_the_c_abi(hip_lib):
     out = torch.full((m, n), float("nan"), device=DEV)
     try:
         assert hip_lib.gts_set_option(1, 9) == 0
-        assert hip_lib.gts_linear_fwd_f32(ptr(a), ptr(w), None, None, ptr(b), ptr(out), m, n, k, 0, 1, None, current_stream()) == 0
+        assert hip_lib.gts_linear_fwd_f32(ptr(a), ptr(w), None, None, ptr(b), ptr(out), m, n, k, 0, 1, None, None, current_stream()) == 0
     finally:
         hip_lib.gts_set_option(1, -1)
     want = (a.cpu().double() @ w.cpu().double().t() + b.cpu().double()).clamp(min=0)
@@ -351,6 +351,67 @@ def test_chained_layer_gemms_equal_two_calls_bit_for_bit(m, k0, k1, n, n2):
     gin, gin2 = dense.linear_bwd_input_chain_t(a0, w0, a1, w1, mask, w2)
     want = dense.linear_bwd_input_t(a0, w0, a1, w1, relu_mask=mask)
     assert torch.equal(gin, want) and torch.equal(gin2, dense.linear_bwd_input_t(want, w2))
+
+
+@pytest.mark.parametrize("rows,cols", [(256, 256), (256, 4), (256, 20), (4, 256), (132, 260), (17, 33), (1024, 1024)])
+@pytest.mark.parametrize("transposed", [False, True])
+def test_weights_in_fragment_order_are_the_layout_the_header_states(rows, cols, transposed):
+    """gts_pack_weights_f32: packed[((T * G + g) * 64 + lane) * 4 + e] = B[16 T + (lane & 15)][16 g + 4 (lane >> 4) + e] with
+    B = w (or w^T), zeros past the edges; with transposed=True the same launch also writes w^T row-major."""
+    import numpy as np
+
+    ws = [_rand(rows, cols, seed=10 + q).to(DEV) for q in range(3)]
+    if transposed:
+        plain, packed = dense.pack_weights(ws, transposed=True, want_plain=True)
+        assert all(torch.equal(p, w.t().contiguous()) for p, w in zip(plain, ws))
+    else:
+        packed = dense.pack_weights(ws)
+    for w, got in zip(ws, packed):
+        b = (w.t() if transposed else w).cpu().numpy()
+        n, k = b.shape
+        tiles, groups = (n + 15) // 16, (k + 15) // 16
+        pad = np.zeros((16 * tiles, 16 * groups), np.float32)
+        pad[:n, :k] = b
+        # [T, i16, g, q, e] -> [T, g, q, i16, e]: lane = i16 + 16 q
+        want = pad.reshape(tiles, 16, groups, 4, 4).transpose(0, 2, 3, 1, 4).reshape(-1)
+        assert got.numel() == want.size and np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("m,k0,k1,n,n2", [(34992, 256, 256, 256, 256), (34992, 20, 20, 256, 256), (60000, 256, 256, 256, 256),
+                                          (60000, 4, 4, 256, 256), (35000, 256, 0, 256, 256), (30001, 132, 256, 256, 256),
+                                          (1000, 64, 64, 256, 256), (49999, 132, 0, 256, 64)])
+def test_gemms_reading_weights_in_fragment_order_give_the_same_bits(m, k0, k1, n, n2):
+    """Forward pair, chained forward (mask bits written), transposed input gradient and its chained form with the
+    `packed` copies of their weights (csrc/gts_gemm.hip: a fragment load = 1 KiB of consecutive bytes) against the same
+    calls on the weights as torch stores them: bit for bit — at the reference's batch shape (35 000 rows: 144-row
+    panels), at C2's (60 000: 240-row panels), with reduction tails (20, 132) and at a size where other kernels run and
+    the copies are ignored — and against fp64."""
+    a0, w0 = _rand(m, k0, seed=1).to(DEV), _rand(n, k0, seed=2).to(DEV)
+    a1, w1 = (_rand(m, k1, seed=3).to(DEV), _rand(n, k1, seed=4).to(DEV)) if k1 else (None, None)
+    b, w2, b2 = _rand(n, seed=5).to(DEV), _rand(n2, n, seed=6).to(DEV), _rand(n2, seed=7).to(DEV)
+    mask = _rand(m, n, seed=8).to(DEV)
+    p0, p2 = dense.pack_weights([w0])[0], dense.pack_weights([w2])[0]
+    p1 = dense.pack_weights([w1])[0] if k1 else None
+    bits_a, bits_b = dense.relu_bits_empty(m, n, a0.device).zero_(), dense.relu_bits_empty(m, n, a0.device).zero_()
+    out, out2 = dense.linear_fwd_chain(a0, w0, a1, w1, b, True, w2, b2, True, relu_bits=bits_a)
+    got, got2 = dense.linear_fwd_chain(a0, w0, a1, w1, b, True, w2, b2, True, relu_bits=bits_b, packed=(p0, p1, p2))
+    assert torch.equal(got, out) and torch.equal(got2, out2) and torch.equal(bits_a, bits_b)
+    assert torch.equal(dense.linear_fwd(a0, w0, a1, w1, bias=b, relu=True, packed=(p0, p1)), out)
+    assert torch.equal(dense.linear_fwd(a0, w0, a1, w1, bias=b, relu=True, packed=(None, p1)), out)      # one copy only
+    # the same operands as TRANSPOSED weights of an input gradient: w0 [n, k0] = (W0)^T with W0 [k0, n] ...
+    gin, gin2 = dense.linear_bwd_input_chain_t(a0, w0, a1, w1, mask, w2, relu_bits=bits_a)
+    hin, hin2 = dense.linear_bwd_input_chain_t(a0, w0, a1, w1, mask, w2, relu_bits=bits_a, packed=(p0, p1, p2))
+    assert torch.equal(hin, gin) and torch.equal(hin2, gin2)
+    assert torch.equal(dense.linear_bwd_input_t(a0, w0, a1, w1, relu_mask=mask, packed=(p0, p1)), gin.clone() if False else
+                       dense.linear_bwd_input_t(a0, w0, a1, w1, relu_mask=mask))
+    ref = a0.cpu().double() @ w0.cpu().double().t() + b.cpu().double()
+    bound = a0.cpu().double().abs() @ w0.cpu().double().abs().t() + b.cpu().double().abs()
+    if k1:
+        ref += a1.cpu().double() @ w1.cpu().double().t()
+        bound += a1.cpu().double().abs() @ w1.cpu().double().abs().t()
+    _check(got, ref.clamp(min=0), bound)
+    with pytest.raises(Exception, match="fragment-order copy"):
+        dense.linear_fwd(a0, w0, a1, w1, bias=b, relu=True, packed=(p2[:-4], p1))
 
 
 @pytest.mark.parametrize("m,k0,k1,n", [(60000, 256, 256, 256), (60000, 4, 4, 256), (49999, 132, 0, 128), (1000, 64, 64, 256),

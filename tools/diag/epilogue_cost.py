@@ -19,8 +19,8 @@ def timeit(fn, reps=40):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) * 1e3 / reps
 for rep in range(2):
-    for name, fn in (("single plain      ", lambda: lib.gts_linear_fwd_f32(P(x), P(w), None, None, None, P(out), M, F, F, 0, 0, None, st)),
-                     ("single bias + relu", lambda: lib.gts_linear_fwd_f32(P(x), P(w), None, None, P(b), P(out), M, F, F, 0, 1, None, st)),
-                     ("pair plain        ", lambda: lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), None, P(out), M, F, F, F, 0, None, st)),
-                     ("pair bias + relu  ", lambda: lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), P(b), P(out), M, F, F, F, 1, None, st))):
+    for name, fn in (("single plain      ", lambda: lib.gts_linear_fwd_f32(P(x), P(w), None, None, None, P(out), M, F, F, 0, 0, None, None, st)),
+                     ("single bias + relu", lambda: lib.gts_linear_fwd_f32(P(x), P(w), None, None, P(b), P(out), M, F, F, 0, 1, None, None, st)),
+                     ("pair plain        ", lambda: lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), None, P(out), M, F, F, F, 0, None, None, st)),
+                     ("pair bias + relu  ", lambda: lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), P(b), P(out), M, F, F, F, 1, None, None, st))):
         print(name, f"{timeit(fn):7.1f} us", flush=True)

@@ -62,7 +62,8 @@ extern "C" int gts_probe_linear_fwd(const float* a0, const float* w0, const floa
   p.ra = static_cast<int>(m), p.rb = static_cast<int>(n), p.c = out, p.ldc = static_cast<int>(n);
   p.bias = bias, p.relu = relu;
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
-  if (a_hot) p.lda[0] = p.lda[1] = 0;
+  if (a_hot & 1) p.lda[0] = p.lda[1] = 0;
+  if (a_hot & 2) p.ldb[0] = p.ldb[1] = 0;   // every weight row of a tile is the same row: a fragment load touches one 64-byte piece
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (variant) {
     case 3: return launch_tiles<64, 256, 2, 4, true, true, false, StampProbe>(p, 1, 1, st);
@@ -70,6 +71,10 @@ extern "C" int gts_probe_linear_fwd(const float* a0, const float* w0, const floa
     case 9: return launch_rows240<StampProbe>(p, st);
     case 10: return launch_panel_direct<3, 4, 1, StampProbe>(p, st);
     case 110: return launch_panel_direct<3, 4, 1, WaveProbe>(p, st);
+    // the reference's batch size (35 000 rows): 144-row panels, fragments 1 / 2 / 3 reduction groups ahead
+    case 1441: return launch_panel_direct<3, 4, 1, StampProbe, 144>(p, st);
+    case 1442: return launch_panel_direct<3, 4, 2, StampProbe, 144>(p, st);
+    case 1443: return launch_panel_direct<3, 4, 3, StampProbe, 144>(p, st);
     case 11: return launch_panel_direct<1, 4, 1, StampProbe>(p, st);
     case 12: return launch_panel_direct<1, 4, 2, StampProbe>(p, st);
     default: return launch_tiles<128, 256, 2, 4, true, true, false, StampProbe>(p, 1, 1, st);

@@ -40,11 +40,11 @@ lib.gts_set_option(1, 10)
 lib.gts_set_option(3, 10)
 for sched in [int(v) for v in sys.argv[1].split(",")]:
     lib.gts_set_option(7, sched)
-    r = [timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), None, None, P(b), P(out), M, F, F, 0, 1, None, st)),
-         timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), P(b), P(out), M, F, F, F, 1, None, st)),
-         timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), P(b), P(out), M, F, F, F, 1, P(bits), st)),
-         timeit(lambda: lib.gts_linear_bwd_input_t_f32(P(x), P(w), P(y), P(w2), None, None, P(out), M, F, F, F, st)),
-         timeit(lambda: lib.gts_linear_bwd_input_t_f32(P(x), P(w), P(y), P(w2), P(x), None, P(out), M, F, F, F, st)),
-         timeit(lambda: lib.gts_linear_bwd_input_t_f32(P(x), P(w), P(y), P(w2), P(x), P(bits), P(out), M, F, F, F, st))]
+    r = [timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), None, None, P(b), P(out), M, F, F, 0, 1, None, None, st)),
+         timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), P(b), P(out), M, F, F, F, 1, None, None, st)),
+         timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), P(b), P(out), M, F, F, F, 1, P(bits), None, st)),
+         timeit(lambda: lib.gts_linear_bwd_input_t_f32(P(x), P(w), P(y), P(w2), None, None, P(out), M, F, F, F, None, st)),
+         timeit(lambda: lib.gts_linear_bwd_input_t_f32(P(x), P(w), P(y), P(w2), P(x), None, P(out), M, F, F, F, None, st)),
+         timeit(lambda: lib.gts_linear_bwd_input_t_f32(P(x), P(w), P(y), P(w2), P(x), P(bits), P(out), M, F, F, F, None, st))]
     print(f"sched {sched:3d}: single {r[0]:7.1f} us | pair {r[1]:7.1f} | pair+bits out {r[2]:7.1f} | igrad pair: no mask {r[3]:7.1f}"
           f" float mask {r[4]:7.1f} bit mask {r[5]:7.1f}", flush=True)

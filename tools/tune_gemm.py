@@ -44,7 +44,7 @@ VARIANTS = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8
 
 def check(v):
     """Both GEMM kinds of variant v against torch (fp32 library GEMM): max error relative to the scale."""
-    lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), P(b), P(out), M, F, F, F, 1, None, st)
+    lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), P(b), P(out), M, F, F, F, 1, None, None, st)
     want = torch.relu(x @ w.t() + y @ w2.t() + b)
     e1 = float((out - want).abs().max() / want.abs().max())
     lib.gts_linear_bwd_input_f32(P(x), P(w), P(y), P(w2), P(x), P(out), M, F, F, F, st)
@@ -58,8 +58,8 @@ for v in VARIANTS:
     lib.gts_set_option(1, v)
     lib.gts_set_option(3, v)
     err = check(v)
-    r = [timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), None, None, P(b), P(out), M, F, F, 0, 1, None, st), g1),
-         timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), P(b), P(out), M, F, F, F, 1, None, st), 2 * g1),
+    r = [timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), None, None, P(b), P(out), M, F, F, 0, 1, None, None, st), g1),
+         timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), P(b), P(out), M, F, F, F, 1, None, None, st), 2 * g1),
          timeit(lambda: lib.gts_linear_bwd_input_f32(P(x), P(w), None, None, None, P(out), M, F, F, 0, st), g1),
          timeit(lambda: lib.gts_linear_bwd_input_f32(P(x), P(w), P(y), P(w2), P(x), P(out), M, F, F, F, st), 2 * g1)]
     print(f"fwd/igrad variant {v}: " + " | ".join(f"{us:7.1f} us {tf:6.1f} TF" for us, tf in r)

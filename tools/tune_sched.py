@@ -21,6 +21,6 @@ for rep in range(2):
     for v in (8, 9, 10, 11, 12):
         for sched in [int(a) for a in sys.argv[1].split(",")]:
             lib.gts_set_option(1, v); lib.gts_set_option(7, sched)
-            t1 = timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), None, None, P(b), P(out), M, F, F, 0, 1, None, st))
-            t2 = timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), P(b), P(out), M, F, F, F, 1, None, st))
+            t1 = timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), None, None, P(b), P(out), M, F, F, 0, 1, None, None, st))
+            t2 = timeit(lambda: lib.gts_linear_fwd_f32(P(x), P(w), P(y), P(w2), P(b), P(out), M, F, F, F, 1, None, None, st))
             print(f"variant {v} sched {sched}: single {t1:6.1f} us  pair {t2:6.1f} us", flush=True)
