@@ -4,7 +4,7 @@ set -o pipefail
 OUT=gpurun_out/${1:-r04f}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 600 python -m pytest tests/test_gpu_gemm.py tests/test_gpu_stack.py tests/test_gpu_full_size.py -m gpu -x -q > $OUT/pytest.log 2>&1
+timeout -k 10 600 python -m pytest tests/test_gpu_gemm.py tests/test_gpu_stack.py tests/test_gpu_full_size.py tests/test_gpu_model.py -m gpu -x -q > $OUT/pytest.log 2>&1
 echo "pytest rc=$?"; tail -3 $OUT/pytest.log
 grep -q " passed" $OUT/pytest.log || exit 1
 line() { tail -1 $1 | python -c "

@@ -7,7 +7,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 if [ "$2" != "notest" ]; then
-  timeout -k 10 1000 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1
+  timeout -k 10 1100 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1
   echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
   tail -4 $OUT/pytest_gpu.log
   if grep -q "Memory access fault" $OUT/pytest_gpu.log; then echo "GPU FAULT"; exit 1; fi
@@ -20,8 +20,8 @@ timeout -k 10 300 python bench.py --config c3 --steps 10 --warmup 3 --blocks 5 -
 timeout -k 10 300 python bench.py --config c4 --steps 10 --warmup 3 --blocks 5 --no-cpu-baseline > $OUT/bench_c2_b8.json 2> $OUT/bench_c2_b8.err; line $OUT/bench_c2_b8.json
 timeout -k 10 400 python bench.py --graphs-per-gpu 32 --steps 5 --warmup 2 --blocks 3 --no-cpu-baseline > $OUT/bench_c2_b32.json 2> $OUT/bench_c2_b32.err; line $OUT/bench_c2_b32.json
 timeout -k 10 300 python bench.py --config real --steps 40 --warmup 8 > $OUT/bench_real.json 2> $OUT/bench_real.err; line $OUT/bench_real.json
-timeout -k 10 300 python tools/measure_epoch_throughput.py --config c2 > $OUT/epoch_throughput.jsonl 2> $OUT/epoch.err
-timeout -k 10 300 python tools/measure_epoch_throughput.py --config real >> $OUT/epoch_throughput.jsonl 2>> $OUT/epoch.err
+timeout -k 10 300 python tools/measure_epoch_throughput.py --config c2 --epochs 2 > $OUT/epoch_throughput.jsonl 2> $OUT/epoch.err
+timeout -k 10 300 python tools/measure_epoch_throughput.py --config real --epochs 2 >> $OUT/epoch_throughput.jsonl 2>> $OUT/epoch.err
 cat $OUT/epoch_throughput.jsonl
 # kernel-only durations of the same commands
 prof() { timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$1 -- python bench.py $2 --no-cpu-baseline > $OUT/$1.log 2> $OUT/$1.err; }

@@ -14,8 +14,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import summarize_rocprof  # noqa: E402
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
-src, dst = f"gpurun_out/{tag}", "profiles"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
+src, root = f"gpurun_out/{tag}", "profiles"
+# from round 4 on a round's files live in profiles/<round>/ (the JSON files bench.py reads stay in profiles/)
+dst = os.path.join(root, rnd) if rnd >= "r04" else root
+os.makedirs(dst, exist_ok=True)
 
 
 def last_json_line(path):
@@ -27,7 +30,7 @@ for name in ("c2", "c3", "c5", "c2_b8", "c2_b32", "real"):
     with open(f"{dst}/{rnd}_bench_{name}.json", "w") as fh:
         fh.write(last_json_line(f"{src}/bench_{name}.json") + "\n")
 for name in ("pmc_traffic.json", "pmc_traffic_b8.json", "pmc_traffic_b32.json", "pmc_traffic_c3.json"):
-    shutil.copy(f"{src}/{name}", f"{dst}/{name}")
+    shutil.copy(f"{src}/{name}", f"{root}/{name}")
 shutil.copy(f"{src}/aux_kernels.jsonl", f"{dst}/{rnd}_aux_kernels.jsonl")
 shutil.copy(f"{src}/epoch_throughput.jsonl", f"{dst}/{rnd}_epoch_throughput.jsonl")
 
@@ -70,7 +73,7 @@ def first_mean(rows, needles):
 
 
 panel, panel_calls = mean_us(c2, ("gemm_panel_direct_kernel<3, 4, 1",))
-avg = {"source": f"profiles/{rnd}_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 5 --blocks 2 "
+avg = {"source": f"{dst}/{rnd}_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 5 --blocks 2 "
                  "--no-cpu-baseline`, kernel-only durations)",
        "gemm_panel_direct_avg_us": panel, "gemm_panel_direct_calls": panel_calls,
        "gemm_wgrad_256x256_avg_us": mean_us(c2, ("wgrad_stream_kernel",) if any("wgrad_stream_kernel" in n for n in c2)
@@ -80,8 +83,8 @@ for tag, rows, label in (("", c2, "C2"), ("b8_", b8, "--config c4 (8 graphs per 
         us, calls, form = first_mean(rows, needles)
         avg[f"{tag}{key}_avg_us"], avg[f"{tag}{key}_form"] = us, form
     if tag:
-        avg[f"{tag}source"] = f"profiles/{rnd}_bench_c2_{tag[:-1]}_kernel_stats.csv ({label})"
-avg["c3_source"] = f"profiles/{rnd}_bench_c3_kernel_stats.csv (--config c3)"
+        avg[f"{tag}source"] = f"{dst}/{rnd}_bench_c2_{tag[:-1]}_kernel_stats.csv ({label})"
+avg["c3_source"] = f"{dst}/{rnd}_bench_c3_kernel_stats.csv (--config c3)"
 # hidden-layer launches only (D = 256); the clustered form of a call = its weight pass + the streaming kernel
 for key, plain, clustered in (("gat_fwd", "gat_fwd_kernel<4, 64>", ("gat_cluster_stream_kernel<0,", "gat_weights_one_chunk_kernel<false>")),
                               ("gat_bwd_edge", "gat_bwd_edge_kernel<4, 64>", ("gat_cluster_stream_kernel<2,", "gat_edge_finish_kernel")),
@@ -93,5 +96,5 @@ for key, plain, clustered in (("gat_fwd", "gat_fwd_kernel<4, 64>", ("gat_cluster
     else:
         avg[f"{key}_avg_us"] = mean_us(c3, (plain,))[0] if any(plain in n for n in c3) else None
         avg[f"{key}_form"] = "plain"
-json.dump(avg, open(f"{dst}/rocprof_kernel_avg.json", "w"), indent=1)
+json.dump(avg, open(f"{root}/rocprof_kernel_avg.json", "w"), indent=1)
 print(json.dumps(avg, indent=1))
