@@ -2085,7 +2085,8 @@ extern "C" int64_t gts_gat_fc_scores_workspace(int64_t m, int64_t heads, int64_t
 
 extern "C" int32_t gts_gat_fc_scores_f32(const float* h, const float* w_fc, const float* attn_l, const float* attn_r,
                                          float* ft, float* el, float* er, float* workspace, int64_t workspace_bytes,
-                                         int64_t m, int64_t heads, int64_t dim, int64_t k, void* stream) {
+                                         int64_t m, int64_t heads, int64_t dim, int64_t k, const float* w_fc_packed,
+                                         void* stream) {
   using namespace gts;
   if (!h || !w_fc || !attn_l || !attn_r || !ft || !el || !er) return GTS_ERR_NULL;
   const int64_t n = heads * dim;
@@ -2097,6 +2098,7 @@ extern "C" int32_t gts_gat_fc_scores_f32(const float* h, const float* w_fc, cons
   p.kseg[0] = static_cast<int>(k), p.kseg[1] = 0;
   p.ra = static_cast<int>(m), p.rb = static_cast<int>(n), p.c = ft, p.ldc = static_cast<int>(n);
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK;
+  p.bp[0] = w_fc_packed;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int parts = static_cast<int>(dim / 64);
   const bool fuse = dim % 64 == 0 && pick_plain_variant<true, true>(p) == 10 &&
@@ -2233,7 +2235,7 @@ extern "C" int64_t gts_linear_bwd_input_t_act_workspace(int64_t m, int64_t k) {
 extern "C" int32_t gts_linear_bwd_input_t_act_f32(const float* g0, const float* w0t, const float* g1, const float* w1t,
                                                   const float* act_out, int32_t activation, float* gin, float* g_bias,
                                                   float* workspace, int64_t workspace_bytes, int64_t m, int64_t k,
-                                                  int64_t n0, int64_t n1, void* stream) {
+                                                  int64_t n0, int64_t n1, const float* const* packed, void* stream) {
   using namespace gts;
   if (!g0 || !w0t || !gin || !act_out || ((g1 == nullptr) != (w1t == nullptr)) || (g_bias && !workspace)) return GTS_ERR_NULL;
   if (activation != 1 && activation != 2) return GTS_ERR_ARGKIND;
@@ -2249,6 +2251,7 @@ extern "C" int32_t gts_linear_bwd_input_t_act_f32(const float* g0, const float* 
   p.lda[1] = p.ldb[1] = static_cast<int>(n1), p.kseg[1] = g1 ? static_cast<int>(n1) : 0;
   p.ra = static_cast<int>(m), p.rb = static_cast<int>(k), p.c = gin, p.ldc = static_cast<int>(k);
   p.tiles_per_split = (p.kseg[0] + kBK - 1) / kBK + (p.kseg[1] + kBK - 1) / kBK;
+  if (packed != nullptr) p.bp[0] = packed[0], p.bp[1] = g1 ? packed[1] : nullptr;
   if (activation == 1 && g_bias && act_fold_in_epilogue(p)) {
     const int rows = panel_rows_for(p.ra, p.rb / kC240);
     const int row_blocks = (p.ra + rows - 1) / rows * 3;

@@ -10,7 +10,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgts_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "gts_hip.h")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -59,12 +59,12 @@ SIGNATURES = {
     "gts_linear_bwd_input_f32": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "gts_linear_bwd_input_t_f32": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p],
     "gts_linear_bwd_input_t_act_workspace": [_i64, _i64],
-    "gts_linear_bwd_input_t_act_f32": [_p, _p, _p, _p, _p, _i32, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "gts_linear_bwd_input_t_act_f32": [_p, _p, _p, _p, _p, _i32, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p],
     "gts_transpose_batch_f32": [_p, _p, _i32, _i64, _i64, _p],
     "gts_packed_weight_floats": [_i64, _i64],
     "gts_pack_weights_f32": [_p, _p, _p, _i32, _i64, _i64, _i32, _p],
     "gts_gat_fc_scores_workspace": [_i64, _i64, _i64],
-    "gts_gat_fc_scores_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "gts_gat_fc_scores_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p],
     "gts_linear_fwd_chain_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _i64, _i32, _p, _p, _p],
     "gts_linear_bwd_input_chain_t_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p],
     "gts_linear_bwd_weight_workspace": [_i64, _i64, _i64, _i32],

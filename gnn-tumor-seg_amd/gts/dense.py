@@ -353,7 +353,7 @@ def linear_bwd_input_t(g0, w0t, g1=None, w1t=None, relu_mask=None, relu_bits=Non
     return gin
 
 
-def linear_bwd_input_t_act(g0, w0t, act_out, activation, g1=None, w1t=None, want_bias_grad=True):
+def linear_bwd_input_t_act(g0, w0t, act_out, activation, g1=None, w1t=None, want_bias_grad=True, packed=None):
     """(gin, g_bias): linear_bwd_input_t carried through the activation of the layer BELOW, whose output `act_out` [M,K] is
     this layer's input (activation 1 = ELU, 2 = ReLU): gin = (g0 @ w0t^T (+ g1 @ w1t^T)) * act'(act_out), g_bias = gin.sum(0)
     — at the tall 256-column-block shapes inside the GEMM's epilogue, otherwise as the pass of its own; the same gin
@@ -377,9 +377,10 @@ def linear_bwd_input_t_act(g0, w0t, act_out, activation, g1=None, w1t=None, want
     g_bias = torch.empty(k, dtype=torch.float32, device=dev) if want_bias_grad else None
     nbytes = lib.gts_linear_bwd_input_t_act_workspace(m, k) if want_bias_grad else 0
     ws = _workspace(dev, nbytes) if want_bias_grad else None
+    table = _packed_array(packed, (w0t, w1t))
     _timed("igrad", 2.0 * m * k * (n0 + n1), lambda: check(
         lib.gts_linear_bwd_input_t_act_f32(ptr(g0), ptr(w0t), ptr(g1), ptr(w1t), ptr(act_out), activation, ptr(gin),
-                                           ptr(g_bias), ptr(ws), nbytes, m, k, n0, n1, current_stream()),
+                                           ptr(g_bias), ptr(ws), nbytes, m, k, n0, n1, table, current_stream()),
         "gts_linear_bwd_input_t_act_f32"))
     return gin, g_bias
 

@@ -593,6 +593,17 @@ FUSE_GAT_SCORES = os.environ.get("GTS_FUSE_GAT_SCORES", "1") != "0"   # el / er 
 FOLD_GAT_ACT_BWD = os.environ.get("GTS_FOLD_GAT_ACT", "1") != "0"   # A/B switch of ActLink
 
 
+PACK_GAT_WEIGHTS = os.environ.get("GTS_PACK_GAT", "1") != "0"   # A/B switch: fragment-order copies of fc / res_fc weights
+
+
+def _turn(ws):
+    """(W^T row-major, W^T in fragment order or Nones) of same-shape weights, one launch (dense.pack_weights)."""
+    if PACK_GAT_WEIGHTS:
+        plain, packed = dense.pack_weights(ws, transposed=True, want_plain=True)
+        return plain, tuple(packed) if len(packed) > 1 else (packed[0], None)
+    return dense.transpose_batch(ws), (None, None)
+
+
 class ActLink:
     """Joins a GATConv layer to the ONE layer that consumes its activated output (GAT.forward, reference
     model/networks.py:61-63: `h = self.layers[l](g, h).flatten(1)` feeds only the next layer).  In the backward pass the
@@ -623,6 +634,8 @@ class _GATLayer(torch.autograd.Function):
         n = h.shape[0]
         al, ar = attn_l.reshape(heads, dim), attn_r.reshape(heads, dim)
         if FUSE_GAT_SCORES and h.shape[1] % 4 == 0:
+            # (fc.weight in fragment order buys the 1024-wide forward nothing — 593 against 591 us with the copy's launch,
+            # profiles/r04 — so only the backward, whose transposes come with the copy for free, passes one)
             ft, el, er = ops.gat_fc_scores(h, w_fc, al, ar, heads, dim)     # el / er in the GEMM epilogue when tall
         else:
             ft = dense.linear_fwd(h, w_fc).view(n, heads, dim)
@@ -667,21 +680,23 @@ class _GATLayer(torch.autograd.Function):
         if w_res is not None:
             (g_wfc, _), (g_wres, _) = dense.linear_bwd_weight_multi([(gft2, h, False), (g_pre, h, False)])
             if fold:
-                wt = dense.transpose_batch([w_fc, w_res])
-                gh, ctx.below.g_bias = dense.linear_bwd_input_t_act(gft2, wt[0], h, act_below, g_pre, wt[1])
+                wt, wtp = _turn([w_fc, w_res])
+                gh, ctx.below.g_bias = dense.linear_bwd_input_t_act(gft2, wt[0], h, act_below, g_pre, wt[1], packed=wtp)
                 ctx.below.folded = True
             elif turn:
-                wt = dense.transpose_batch([w_fc, w_res])
-                gh = dense.linear_bwd_input_t(gft2, wt[0], g_pre, wt[1])
+                wt, wtp = _turn([w_fc, w_res])
+                gh = dense.linear_bwd_input_t(gft2, wt[0], g_pre, wt[1], packed=wtp)
             else:
                 gh = dense.linear_bwd_input(gft2, w_fc, g_pre, w_res) if need[1] else None
         else:
             g_wfc, _ = dense.linear_bwd_weight(gft2, h)
             if fold:
-                gh, ctx.below.g_bias = dense.linear_bwd_input_t_act(gft2, dense.transpose_batch([w_fc])[0], h, act_below)
+                wt, wtp = _turn([w_fc])
+                gh, ctx.below.g_bias = dense.linear_bwd_input_t_act(gft2, wt[0], h, act_below, packed=(wtp[0], None))
                 ctx.below.folded = True
             elif turn:
-                gh = dense.linear_bwd_input_t(gft2, dense.transpose_batch([w_fc])[0])
+                wt, wtp = _turn([w_fc])
+                gh = dense.linear_bwd_input_t(gft2, wt[0], packed=(wtp[0], None))
             else:
                 gh = dense.linear_bwd_input(gft2, w_fc) if need[1] else None
             if gh is not None and ctx.identity_res:

@@ -336,9 +336,10 @@ def gat_scores(ft, attn_l, attn_r):
     return el, er
 
 
-def gat_fc_scores(h, w_fc, attn_l, attn_r, heads, dim):
+def gat_fc_scores(h, w_fc, attn_l, attn_r, heads, dim, packed=None):
     """(ft [N,H,D], el [N,H], er [N,H]) = (h @ w_fc^T viewed [N,H,D], <ft, attn_l>, <ft, attn_r>): GATConv's projection
-    with the attention scores computed in the GEMM's epilogue when the operands are tall (else GEMM + gat_scores)."""
+    with the attention scores computed in the GEMM's epilogue when the operands are tall (else GEMM + gat_scores).
+    packed: dense.pack_weights copy of w_fc (fragment order; read by the panel kernels, same values)."""
     h, w_fc = h.contiguous(), w_fc.contiguous()
     attn_l, attn_r = attn_l.reshape(heads, dim).contiguous(), attn_r.reshape(heads, dim).contiguous()
     _f32(h, w_fc, attn_l, attn_r)
@@ -357,9 +358,11 @@ def gat_fc_scores(h, w_fc, attn_l, attn_r, heads, dim):
     nbytes = lib.gts_gat_fc_scores_workspace(n, heads, dim)
     ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=h.device)
     from . import dense
+    if packed is not None:
+        dense._packed_array((packed,), (w_fc,))      # size check only
     dense._timed("fwd", 2.0 * n * heads * dim * k, lambda: check(lib.gts_gat_fc_scores_f32(
         ptr(h), ptr(w_fc), ptr(attn_l), ptr(attn_r), ptr(ft), ptr(el), ptr(er), ptr(ws), ws.numel() * 4, n, heads, dim, k,
-        current_stream()), "gts_gat_fc_scores_f32"))
+        ptr(packed), current_stream()), "gts_gat_fc_scores_f32"))
     return ft, el, er
 
 

@@ -339,7 +339,8 @@ int64_t gts_linear_bwd_input_t_act_workspace(int64_t m, int64_t k);
 int32_t gts_linear_bwd_input_t_act_f32(const float* g0, const float* w0t, const float* g1, const float* w1t,
                                        const float* act_out, int32_t activation, float* gin, float* g_bias,
                                        float* workspace, int64_t workspace_bytes, int64_t m, int64_t k,
-                                       int64_t n0, int64_t n1, void* stream);
+                                       int64_t n0, int64_t n1, const float* const* packed,
+                                       void* stream);
 /* GATConv's projection with its attention scores (model/networks.py:46,52,56 -> dgl GATConv: feat_src = fc(h).view(N, H, D);
  * el = (feat_src * attn_l).sum(-1); er likewise):  ft [m, heads*dim] = h [m, k] w_fc^T,  el/er [m, heads] = <ft[n,h,:], attn_l/r[h,:]>.
  * Tall operands with dim % 64 == 0: the dot products ride in the GEMM epilogue (partials per 64 columns in `workspace`,
@@ -347,7 +348,7 @@ int32_t gts_linear_bwd_input_t_act_f32(const float* g0, const float* w0t, const 
 int64_t gts_gat_fc_scores_workspace(int64_t m, int64_t heads, int64_t dim);
 int32_t gts_gat_fc_scores_f32(const float* h, const float* w_fc, const float* attn_l, const float* attn_r,
                               float* ft, float* el, float* er, float* workspace, int64_t workspace_bytes,
-                              int64_t m, int64_t heads, int64_t dim, int64_t k, void* stream);
+                              int64_t m, int64_t heads, int64_t dim, int64_t k, const float* w_fc_packed, void* stream);
 /* two GEMMs of a layer chain in one call (one launch when the operands are tall and <= 256 wide, otherwise two):
  *   out  [m, n]  = act (a0 w0^T (+ a1 w1^T) + bias)          exactly gts_linear_fwd_f32
  *   out2 [m, n2] = act2(out w2^T + bias2)                      exactly gts_linear_fwd_f32 on `out`
