@@ -404,193 +404,8 @@ constexpr int kR240 = 240, kC240 = 256, kWm240 = 3, kWn240 = 4, kThreads240 = 64
 constexpr int kTm240 = kR240 / kWm240 / 16, kTn240 = kC240 / kWn240 / 16;   // 5 x 4 tiles per wave
 constexpr int kStage240 = 16 * (kC240 / kWn240 + 4);                       // per-wave epilogue patch [16][68]
 
-template <class Probe = NoProbe>
-__global__ __launch_bounds__(kThreads240, kWm240 * kWn240 / 4) void gemm_rows240_kernel(const GemmArgs p) {
-  constexpr int kAFloats = kR240 * kKcLd, kBFloats = kC240 * kKcLd, kImage = kAFloats + kBFloats;
-  constexpr int kAVec = (kR240 + 95) / 96, kBVec = (kC240 + 95) / 96;       // 3 + 3 float4 per thread and tile
-  static_assert(kThreads240 == 8 * 96, "the loader assumes 96 rows of 8 float4 per pass");
-  static_assert(2 * kImage >= kWm240 * kWn240 * kStage240, "epilogue patches reuse the operand area");
-  __shared__ float lds[2 * kImage];
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave / kWn240, wn = wave % kWn240;
-  const int i16 = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.x * kR240, n0 = blockIdx.y * kC240;
-  const int row_end = min(p.ra, m0 + kR240);       // rows past the panel belong to the next workgroup
-  const int nt0 = (p.kseg[0] + kBK - 1) / kBK, nt1 = (p.kseg[1] + kBK - 1) / kBK;
-  const int n_tiles = nt0 + nt1;
-
-  v4acc acc[kTm240][kTn240];
-#pragma unroll
-  for (int tm = 0; tm < kTm240; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < kTn240; ++tn) acc[tm][tn] = v4acc{0.f, 0.f, 0.f, 0.f};
-
-  // Operand staging.  768 threads, 8 float4 per 32-wide row: thread t owns (row t >> 3, columns
-  // 4 (t & 7) ..) of three row groups 96 rows apart, so one lane offset serves every slot and the
-  // slot / panel / reduction-tile part of the address is wave-uniform.
-  const int r0 = threadIdx.x >> 3, kk = (threadIdx.x & 7) * 4;
-  bool a_ok[kAVec], b_ok[kBVec];
-#pragma unroll
-  for (int s = 0; s < kAVec; ++s) a_ok[s] = r0 + 96 * s < kR240 && m0 + r0 + 96 * s < row_end;
-#pragma unroll
-  for (int s = 0; s < kBVec; ++s) b_ok[s] = r0 + 96 * s < kC240 && n0 + r0 + 96 * s < p.rb;
-  v4f ra[kAVec], rb[kBVec];
-  auto fetch = [&](int t) {
-    const bool second = t >= nt0;
-    const int lda = second ? p.lda[1] : p.lda[0], ldb = second ? p.ldb[1] : p.ldb[0];
-    const int k0 = (second ? t - nt0 : t) * kBK, n_k = second ? p.kseg[1] : p.kseg[0];
-    const float* a = (second ? p.a[1] : p.a[0]) + static_cast<size_t>(m0) * lda + k0;   // uniform
-    const float* b = (second ? p.b[1] : p.b[0]) + static_cast<size_t>(n0) * ldb + k0;
-    const unsigned off_a = static_cast<unsigned>(r0) * lda + kk, off_b = static_cast<unsigned>(r0) * ldb + kk;
-    const bool k_ok = k0 + kk < n_k;
-#pragma unroll
-    for (int s = 0; s < kAVec; ++s)
-      ra[s] = (a_ok[s] && k_ok) ? *reinterpret_cast<const v4f*>(a + static_cast<size_t>(96 * s) * lda + off_a)
-                                : v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < kBVec; ++s)
-      rb[s] = (b_ok[s] && k_ok) ? *reinterpret_cast<const v4f*>(b + static_cast<size_t>(96 * s) * ldb + off_b)
-                                : v4f{0.f, 0.f, 0.f, 0.f};
-  };
-  const int lds_slot = r0 * kKcLd + kk;
-  auto stash = [&](int image) {
-    float* la = lds + image * kImage + lds_slot;
-    float* lb = la + kAFloats;
-#pragma unroll
-    for (int s = 0; s < kAVec; ++s)
-      if (r0 + 96 * s < kR240) *reinterpret_cast<v4f*>(la + 96 * s * kKcLd) = ra[s];
-#pragma unroll
-    for (int s = 0; s < kBVec; ++s)
-      if (r0 + 96 * s < kC240) *reinterpret_cast<v4f*>(lb + 96 * s * kKcLd) = rb[s];
-  };
-  // Per 16-deep reduction group: the wave's five A fragments stay in registers while the four B
-  // fragments pass through one at a time (the next one is requested before the current one's 20
-  // MFMAs are issued).  Consecutive MFMAs write different accumulators.
-  auto compute = [&](int image) {
-    const float* la = lds + image * kImage + (wm * (kR240 / kWm240) + i16) * kKcLd + 4 * q;
-    const float* lb = lds + image * kImage + kAFloats + (wn * (kC240 / kWn240) + i16) * kKcLd + 4 * q;
-#pragma unroll
-    for (int g = 0; g < kBK / 16; ++g) {
-      if (p.sched & 1) {
-        if (g == 0) __builtin_amdgcn_s_setprio(2);
-        else __builtin_amdgcn_s_setprio(0);
-      }
-      v4f af[kTm240];
-#pragma unroll
-      for (int tm = 0; tm < kTm240; ++tm) af[tm] = *reinterpret_cast<const v4f*>(la + tm * 16 * kKcLd + g * 16);
-      v4f bf = *reinterpret_cast<const v4f*>(lb + g * 16);
-#pragma unroll
-      for (int tn = 0; tn < kTn240; ++tn) {
-        v4f next = bf;
-        if (tn + 1 < kTn240) next = *reinterpret_cast<const v4f*>(lb + (tn + 1) * 16 * kKcLd + g * 16);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int tm = 0; tm < kTm240; ++tm)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tm][j], bf[j], acc[tm][tn], 0, 0, 0);
-        bf = next;
-      }
-    }
-  };
-
-  Probe::mark(0);
-  if (n_tiles > 0) {
-    fetch(0);
-    stash(0);
-    if (n_tiles > 1) fetch(1);
-    __syncthreads();
-  }
-  Probe::mark(1);
-  for (int t = 0; t < n_tiles; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < n_tiles) stash(cur ^ 1);   // tile t+1: requested one iteration ago
-    if (t + 2 < n_tiles) fetch(t + 2);     // lands under the MFMAs below
-    compute(cur);
-    __syncthreads();                       // image cur^1 complete; everyone is done reading image cur
-  }
-  Probe::mark(2);
-
-  // Epilogue.  C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r.  A row of
-  // four tiles (16 x 64 outputs) goes through the wave's LDS patch and leaves as 16-byte-per-lane
-  // row segments (256 contiguous bytes per 16 lanes) with bias / ReLU / mask applied as float4.
-  float* stage = lds + wave * kStage240;
-  constexpr int kLd = kC240 / kWn240 + 4;
-  const bool wide = (p.rb & 3) == 0 && (p.ldc & 3) == 0;
-  const int c4 = i16 * 4;
-  const int col = n0 + wn * (kC240 / kWn240) + c4;
-  const bool col_ok = col < p.rb;
-  v4f bias = {0.f, 0.f, 0.f, 0.f};
-  if (wide && p.bias != nullptr && col_ok) bias = *reinterpret_cast<const v4f*>(p.bias + col);
-#pragma unroll
-  for (int tm = 0; tm < kTm240; ++tm) {
-    const int row_base = m0 + wm * (kR240 / kWm240) + tm * 16;
-    if (wide) {
-      v4f mk[4];
-      if (p.mask != nullptr) {   // requested first: the latency hides behind the LDS staging
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int row = row_base + it * 4 + q;
-          mk[it] = (row < row_end && col_ok)
-                       ? *reinterpret_cast<const v4f*>(p.mask + static_cast<size_t>(row) * p.ldc + col)
-                       : v4f{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-#pragma unroll
-      for (int tn = 0; tn < kTn240; ++tn)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) stage[(4 * q + r) * kLd + tn * 16 + i16] = acc[tm][tn][r];
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int lrow = it * 4 + q, row = row_base + lrow;
-        v4f val = *reinterpret_cast<const v4f*>(stage + lrow * kLd + c4) + bias;
-        if (row < row_end && col_ok) {
-          if (p.relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
-          }
-          if (p.mask != nullptr) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) val[e] = mk[it][e] > 0.f ? val[e] : 0.f;
-          }
-          *reinterpret_cast<v4f*>(p.c + static_cast<size_t>(row) * p.ldc + col) = val;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    } else {
-#pragma unroll
-      for (int tn = 0; tn < kTn240; ++tn) {
-        const int c = n0 + wn * (kC240 / kWn240) + tn * 16 + i16;
-        const float bs = (p.bias != nullptr && c < p.rb) ? p.bias[c] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = row_base + 4 * q + r;
-          if (row < row_end && c < p.rb) {
-            const size_t off = static_cast<size_t>(row) * p.ldc + c;
-            float val = acc[tm][tn][r] + bs;
-            if (p.relu) val = fmaxf(val, 0.f);
-            if (p.mask != nullptr) val = p.mask[off] > 0.f ? val : 0.f;
-            p.c[off] = val;
-          }
-        }
-      }
-    }
-  }
-  Probe::mark(3);
-}
-
-template <class Probe = NoProbe>
-int launch_rows240(const GemmArgs& p, hipStream_t st) {
-  dim3 grid((p.ra + kR240 - 1) / kR240, (p.rb + kC240 - 1) / kC240, 1);
-  GemmArgs q = p;
-  q.sched = g_gemm_sched;
-  gemm_rows240_kernel<Probe><<<grid, kThreads240, 0, st>>>(q);
-  return launch_status();
-}
-
 // ---- 240-row panels, operands straight into MFMA fragments (no LDS staging, no barriers) --------
-// Same panels as gemm_rows240_kernel (240 x 256 outputs per workgroup on the 16x16x4 MFMA), but a
+// 240 x 256 outputs per workgroup on the 16x16x4 MFMA (a form that staged the panels through LDS is in tools/diag); a
 // lane fetches its own fragments from global memory: lane (i, q) of a wave needs
 // A[row i][16 g + 4 q .. + 3] — one 16-byte buffer load — and the 16 lanes of a quarter cover 16
 // rows x 64 contiguous bytes.  No LDS images, no stash, no barrier: the waves of a workgroup are
@@ -767,7 +582,7 @@ __device__ __forceinline__ void panel_stage(const PanelStage s, float* lds, int 
     }
   }
 
-  // Epilogue as in gemm_rows240_kernel: a row of TN tiles (16 x WTN outputs) through the wave's LDS
+  // Epilogue: a row of TN tiles (16 x WTN outputs) through the wave's LDS
   // patch, out as 16-byte row segments with bias / ReLU / mask applied as float4.
   float* stage = lds + wave * kStage;
   const bool wide = G ? (s.rb & 3) == 0 && (s.ldc & 3) == 0 : true;
@@ -1008,284 +823,13 @@ int launch_panel_direct(const GemmArgs& p, hipStream_t st) {
 }
 #undef GTS_PANEL_LAUNCH
 
-// ---- weight gradients, operands straight into MFMA fragments ------------------------------------
-// C[n, k] = sum_m g[m, n] act[m, k] (one split of the node range per blockIdx.z, slabs as above).
-// Both operands have the reduction index m as their ROW index, so a lane cannot fetch four
-// consecutive reduction steps with one load.  It fetches four consecutive COLUMNS instead:
-// lane (c, q) loads g[m + q][nb + 4 c .. + 3] (16 lanes = 256 contiguous bytes of one row) and the
-// four components feed four MFMAs of four INTERLEAVED 16-row tiles (tile t = rows nb + 4 i + t),
-// each consuming the reduction steps m .. m + 3 (one per lane quarter).  The same on the act side;
-// accumulator (t, t') then holds C[nb + 4 (4 q + r) + t][kb + 4 c + t'], so the four t' registers
-// of a lane are one contiguous 16-byte piece of a C row: the tile leaves without any staging.
-// 16 waves of 64 x 64 outputs, no LDS, no barriers; DEPTH + 1 register pairs of fragments per wave
-// (the loads of the next DEPTH reduction steps are in flight under the 16 MFMAs of a step).
-template <int DEPTH, class Probe = NoProbe>
-__global__ __launch_bounds__(1024, 4) void wgrad_direct_kernel(const GemmArgs p) {
-  constexpr int R = DEPTH + 1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int c16 = lane & 15, q = lane >> 4;
-  const int problem = blockIdx.y / p.tiles_n, tile_n = blockIdx.y % p.tiles_n;
-  const int nb = blockIdx.x * 256 + wm * 64, kb = tile_n * 256 + wn * 64;
-  const float* g = kernarg_entry<const float*>(offsetof(GemmArgs, pa), problem);
-  const float* act = kernarg_entry<const float*>(offsetof(GemmArgs, pb), problem);
-  const int ldg = p.lda[0], lda = p.ldb[0];
-  const int m_beg = min(p.kseg[0], static_cast<int>(blockIdx.z) * p.tiles_per_split * kBK);
-  const int m_end = min(p.kseg[0], m_beg + p.tiles_per_split * kBK);
-  // rows [m_beg, m_end) of both operands
-  __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(g + static_cast<size_t>(m_beg) * ldg), 0, (m_end - m_beg) * ldg * 4, 0x00020000);
-  __amdgpu_buffer_rsrc_t ract = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(act + static_cast<size_t>(m_beg) * lda), 0, (m_end - m_beg) * lda * 4, 0x00020000);
-  // lane offsets are loop-invariant (a lane whose four columns lie past the matrix is parked outside
-  // the resource and reads 0); the reduction step advances through the wave-uniform scalar offset
-  const bool g_ok = nb + 4 * c16 < p.ra, a_ok = kb + 4 * c16 < p.rb;
-  const unsigned vg = g_ok ? static_cast<unsigned>(q * ldg + nb + 4 * c16) * 4 : kOutOfRange;
-  const unsigned va = a_ok ? static_cast<unsigned>(q * lda + kb + 4 * c16) * 4 : kOutOfRange;
-
-  v4acc acc[4][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc[t][u] = v4acc{0.f, 0.f, 0.f, 0.f};
-  v4f csum = {0.f, 0.f, 0.f, 0.f};
-  // the column sums of g (bias gradient) ride on ONE wave per row block and SIMD: (wm, wn = wm)
-  const bool want_colsum = p.colsum != nullptr && tile_n == 0 && wn == wm;
-
-  Probe::mark(0);
-  const int steps = (m_end - m_beg) / 4, ragged = (m_end - m_beg) % 4;   // 4 reduction rows per MFMA step
-  v4f gf[R], af[R];
-  auto fetch = [&](int slot, int step) {   // step is clamped by the callers: never past the last whole step
-    gf[slot] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rg, vg, step * ldg * 16, 0));
-    af[slot] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ract, va, step * lda * 16, 0));
-  };
-  auto multiply = [&](int slot, auto with_colsum) {
-    if constexpr (decltype(with_colsum)::value) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) csum[t] += gf[slot][t];
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-        acc[t][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[slot][t], af[slot][v], acc[t][v], 0, 0, 0);
-  };
-  auto reduce = [&](auto with_colsum) {
-    if (steps > 0) {
-#pragma unroll
-      for (int u = 0; u < DEPTH; ++u) fetch(u, min(u, steps - 1));
-    }
-    int s = 0;
-    for (; s + R <= steps; s += R) {
-#pragma unroll
-      for (int u = 0; u < R; ++u) {
-        fetch((u + DEPTH) % R, min(s + u + DEPTH, steps - 1));
-        multiply(u, with_colsum);
-      }
-#pragma unroll
-      for (int u = 0; u < R; ++u) {   // pin the pipeline: a step's two loads in front of the step's MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-        if constexpr (decltype(with_colsum)::value) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < R - 1; ++u)   // the last steps % R steps: their fragments are already on the way
-      if (s + u < steps) multiply(u, with_colsum);
-    if (ragged != 0) {   // 1-3 rows left: the lane quarters past them read outside the resource
-      gf[0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rg, q < ragged ? vg : kOutOfRange, steps * ldg * 16, 0));
-      af[0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ract, q < ragged ? va : kOutOfRange, steps * lda * 16, 0));
-      multiply(0, with_colsum);
-    }
-  };
-  Probe::mark(1);
-  if (want_colsum) reduce(std::true_type{});
-  else reduce(std::false_type{});
-  Probe::mark(2);
-
-  const size_t slab = static_cast<size_t>(problem) * p.n_splits + blockIdx.z;
-  float* c = p.c + slab * p.ra * p.ldc;
-  const int col = kb + 4 * c16;
-  if (col < p.rb) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = nb + 4 * (4 * q + r) + t;
-        if (row < p.ra)
-          *reinterpret_cast<v4f*>(c + static_cast<size_t>(row) * p.ldc + col) =
-              v4f{acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
-      }
-  }
-  if (want_colsum) {   // the four lane quarters hold the rows m = q (mod 4): add them in quarter order
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float q1 = __shfl(csum[t], c16 + 16, kWave), q2 = __shfl(csum[t], c16 + 32, kWave),
-                  q3 = __shfl(csum[t], c16 + 48, kWave);
-      csum[t] = ((csum[t] + q1) + q2) + q3;
-    }
-    if (q == 0 && g_ok) *reinterpret_cast<v4f*>(p.colsum + slab * p.ra + nb + 4 * c16) = csum;
-  }
-  Probe::mark(3);
-}
-
-// ---- weight gradients, operand tiles by LDS-DMA ------------------------------------------------
-// Same 256 x 256 tile, split-reduction slabs and 32x32x2 MFMA reduction order as the
-// double-buffered gemm_kernel<256, 256, 4, 4, false, false, true>, with two changes:
-//   * the [32 rows][256 floats] LDS image of a reduction-strided operand is a byte-for-byte copy
-//     of 32 global row pieces of 1 KiB, so the tiles travel global -> LDS by `buffer_load ... lds`
-//     (one 1 KiB piece per wave instruction, four pieces per wave and tile): no staging registers,
-//     no ds_write, and rows / columns past the operand read as zeros through the buffer resource;
-//   * the single-word fragment reads of MFMA step s are written three steps ahead of their use.
-// Measured (tools/diag/wgrad_stamps.py, profiles/r02_wgrad_stamps.log): exactly the cycles of the
-// register-staged tile — 2.704 M shader cycles per workgroup = 87.9 % of the matrix pipe — and 95.2 %
-// with the LDS fragment reads removed: what bounds both is the ISSUE of the 32 ds_read2_b32 per wave
-// and tile beside the MFMAs (~11 cycles of lost MFMA issue each), not latency and not the tile copy.
-// One barrier per tile, in front of step 13: by then a wave has issued (and waits for) every read of
-// this tile's image and its own DMA pieces of the next tile; after it the next image is complete,
-// this one is free, the DMA of tile t+2 goes into it and steps 13-15 prefetch from the next image.
-template <class Probe = NoProbe, int EXPERIMENT = 0>   // EXPERIMENT != 0: timing experiments of tools/diag only (wrong results)
-__global__ __launch_bounds__(1024, 4) void wgrad_dma_kernel(const GemmArgs p) {
-  constexpr int BM = 256, BN = 256, WM = 4, WN = 4, WTM = 64, WTN = 64, TM = 2, TN = 2;
-  constexpr int kImage = kBK * (BM + BN);   // floats: A image then B image
-  __shared__ float lds[2 * kImage];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int i = lane & 31, h = lane >> 5;
-  const int problem = blockIdx.y / p.tiles_n, tile_n = blockIdx.y % p.tiles_n;
-  const int m0 = blockIdx.x * BM, n0 = tile_n * BN;   // output rows (columns of g) / output columns (columns of act)
-  const float* g = kernarg_entry<const float*>(offsetof(GemmArgs, pa), problem);
-  const float* act = kernarg_entry<const float*>(offsetof(GemmArgs, pb), problem);
-  const int ldg = p.lda[0], lda = p.ldb[0];
-  const int n_tiles_all = (p.kseg[0] + kBK - 1) / kBK;
-  const int t_beg = min(n_tiles_all, static_cast<int>(blockIdx.z) * p.tiles_per_split);
-  const int t_end = min(n_tiles_all, t_beg + p.tiles_per_split);
-  const int row_beg = t_beg * kBK, rows = min(p.kseg[0], t_end * kBK) - row_beg;   // reduction rows of this split
-  __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(g + static_cast<size_t>(row_beg) * ldg), 0, rows * ldg * 4, 0x00020000);
-  __amdgpu_buffer_rsrc_t ract = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(act + static_cast<size_t>(row_beg) * lda), 0, rows * lda * 4, 0x00020000);
-  // wave w copies rows w and w + 16 of both tiles; a lane whose four columns lie past the operand
-  // is parked outside the resource (zeros land in LDS)
-  const bool g_ok = m0 + 4 * lane < p.ra, a_ok = n0 + 4 * lane < p.rb;
-  const unsigned vg = g_ok ? static_cast<unsigned>(wave * ldg + m0 + 4 * lane) * 4 : kOutOfRange;
-  const unsigned va = a_ok ? static_cast<unsigned>(wave * lda + n0 + 4 * lane) * 4 : kOutOfRange;
-  const unsigned tile_g = g_ok ? static_cast<unsigned>(ldg) * kBK * 4 : 0, tile_a = a_ok ? static_cast<unsigned>(lda) * kBK * 4 : 0;
-  const unsigned half_g = g_ok ? static_cast<unsigned>(ldg) * 16 * 4 : 0, half_a = a_ok ? static_cast<unsigned>(lda) * 16 * 4 : 0;
-  auto dma = [&](int t, int image) {   // tile t (counted from t_beg) -> image; row offset in the checked voffset
-    float* ia = lds + image * kImage + wave * BM;
-    float* ib = lds + image * kImage + kBK * BM + wave * BN;
-    const unsigned og = vg + static_cast<unsigned>(t) * tile_g, oa = va + static_cast<unsigned>(t) * tile_a;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, ia, 16, og, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, ia + 16 * BM, 16, og + half_g, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ract, ib, 16, oa, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ract, ib + 16 * BN, 16, oa + half_a, 0, 0, 0);
-  };
-
-  v16f acc[TM][TN];
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-  float csum[TM];
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) csum[tm] = 0.f;
-  const bool want_colsum = p.colsum != nullptr && tile_n == 0 && wn == 0;
-
-  float fa[4][TM], fb[4][TN];
-  auto frag_read = [&](int slot, const float* image, int step) {
-    const int kk = (step >> 2) * 8 + 4 * h + (step & 3);
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) fa[slot][tm] = image[kk * BM + wm * WTM + tm * 32 + i];
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) fb[slot][tn] = image[kBK * BM + kk * BN + wn * WTN + tn * 32 + i];
-  };
-
-  Probe::mark(0);
-  const int n_tiles = t_end - t_beg;
-  if (n_tiles > 0) {
-    dma(0, 0);
-    if (n_tiles > 1) {
-      dma(1, 1);
-      __builtin_amdgcn_s_waitcnt(0x0F70 | 4);   // vmcnt(4): the four pieces of tile 0 have landed
-    } else {
-      __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 3; ++s) frag_read(s, lds, s);
-  }
-  Probe::mark(1);
-  auto mfma_step = [&](int slot) {
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) csum[tm] += want_colsum ? fa[slot][tm] : 0.0f;   // + 0 is exact
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][tm], fb[slot][tn], acc[tm][tn], 0, 0, 0);
-  };
-  for (int t = 0; t < n_tiles; ++t) {
-    const int cur = t & 1;
-    const float* img = lds + cur * kImage;
-    // past the last tile the three look-ahead steps re-read this image (never consumed)
-    const float* img_next = t + 1 < n_tiles ? lds + (cur ^ 1) * kImage : img;
-    // steps 0 .. 12: straight-line code, one scheduling region — per step the two LDS reads of step
-    // s + 3 (a ds_read2_b32 per operand), then the step's MFMAs
-#pragma unroll
-    for (int s = 0; s < 13; ++s) {
-      if (EXPERIMENT != 1) frag_read((s + 3) & 3, img, s + 3);
-      mfma_step(s & 3);
-    }
-#pragma unroll
-    for (int s = 0; s < 13; ++s) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, TM, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-    }
-    if (EXPERIMENT != 2) {
-      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of tile t+1 are in LDS
-      __syncthreads();                       // (+ lgkmcnt(0)) image cur fully read, image cur^1 complete
-      if (t + 2 < n_tiles) dma(t + 2, cur);
-    }
-#pragma unroll
-    for (int s = 13; s < 16; ++s) {
-      if (EXPERIMENT != 1) frag_read((s + 3) & 3, img_next, s + 3 - 16);
-      mfma_step(s & 3);
-    }
-#pragma unroll
-    for (int s = 13; s < 16; ++s) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, TM, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-    }
-  }
-  Probe::mark(2);
-  const size_t slab = static_cast<size_t>(problem) * p.n_splits + blockIdx.z;
-  write_tile<BM, BN, WM, WN>(p, lds, p.c + slab * p.ra * p.ldc, acc, m0, n0);
-  Probe::mark(3);
-  if (want_colsum) {
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const float total = csum[tm] + __shfl_xor(csum[tm], 32, kWave);  // the two kk halves
-      const int row = m0 + wm * WTM + tm * 32 + (lane & 31);
-      if ((lane >> 5) == 0 && row < p.ra) p.colsum[slab * p.ra + row] = total;
-    }
-  }
-}
-
-// out_q[i] = sum_s slab[q][s][i] for problems q, summed in split order inside four interleaved
-// split groups whose partials are then added in group order: a fixed association, so results
-// are bitwise reproducible.  One float4 column per thread-quad.
 // ---- weight gradients, a main loop of MFMAs, LDS reads and nothing else (round 3) -----------------------------------
 // The f32 MFMA and the vector ALU share their arithmetic on gfx950: a vector instruction between two MFMAs costs the
 // wave ~17 cycles of matrix-pipe time, each further one ~4 (profiles/r03_mfma_valu_coissue.log).  The two kernels above
 // carry 20 - 30 of them per reduction tile (fragment addresses, DMA offsets, the bias column sums in every wave): that,
 // not the issue of the LDS reads, is what held them at 87.9 % of the matrix pipe.  Same 256 x 256 tile, slabs, MFMA
 // order and column-sum order as gemm_kernel<256, 256, 4, 4, false, false, true> (bit-identical results), same
-// LDS-DMA tile copies as wgrad_dma_kernel, but:
+// LDS-DMA tile copies (as the rejected wgrad_dma_kernel, tools/diag/gemm_rejected_forms.inc), but:
 //   * LDS holds [A image 0 | A image 1 | B image 0 | B image 1] (32 KiB each), so ONE address register per 32-row
 //     block reaches every fragment element of BOTH images through the immediate offsets of ds_read2st64_b32 (units of
 //     256 B: reduction row r of image I sits 4 r + 128 I units up; a read fetches steps j, j + 1);
@@ -1881,13 +1425,9 @@ int launch_plain(const GemmArgs& p, hipStream_t st) {
         default: return launch_panel_direct<3, 4, 1>(p, st);
       }
     }
-    if (variant == 11) return launch_panel_direct<1, 4, 1>(p, st);
-    if (variant == 12) return launch_panel_direct<1, 4, 2>(p, st);
   }
   // every other tile: the float mask is read as before, and the bits of the output come from a pass of their own
-  int rc = GTS_OK;
-  if (AKC && BKC && variant == 9) rc = launch_rows240(p, st);
-  else rc = launch_plain_tiles<AKC, BKC>(p, variant, st);
+  int rc = launch_plain_tiles<AKC, BKC>(p, variant, st);
   if (rc != GTS_OK || p.bits_out == nullptr) return rc;
   const long long words = static_cast<long long>((p.ra + 3) / 4) * (p.rb >> 6);
   relu_bits_kernel<<<static_cast<unsigned>((words + 3) / 4), 256, 0, st>>>(p.c, p.bits_out, p.ra, p.rb);
@@ -1904,7 +1444,7 @@ inline void wgrad_candidate(int variant, int64_t k, int* bm, int* bn, int64_t* s
   *bm = 128, *bn = k <= 64 ? 64 : 128, *slots = 512;   // 2 workgroups per CU
   if (k <= 64) return;
   if (variant == 2) *bn = 256;
-  if (variant == 4 || variant == 5 || variant == 6 || variant == 7 || variant == 8 || variant == 9) *bm = 256, *bn = 256, *slots = 256;  // one workgroup per CU
+  if (variant == 4 || variant == 6) *bm = 256, *bn = 256, *slots = 256;  // one workgroup per CU
 }
 
 inline WgradPlan wgrad_plan(int64_t m, int64_t n, int64_t k, int n_problems) {
@@ -1950,27 +1490,11 @@ int launch_wgrad(const GemmArgs& p, const WgradPlan& plan, hipStream_t st) {
   switch (plan.variant) {
     case 2: return launch_tiles<128, 256, 2, 4, false, false>(p, np, splits, st);
     case 4: return launch_tiles<256, 256, 4, 4, false, false, true>(p, np, splits, st);
-    case 8: return launch_tiles<256, 256, 2, 4, false, false, true>(p, np, splits, st);   // 8 waves of 128 x 64: 0.375 LDS reads per MFMA
-    case 9: return launch_tiles<256, 256, 4, 2, false, false, true>(p, np, splits, st);   // 8 waves of 64 x 128
     case 6: {
       GemmArgs q = p;
       q.tiles_n = (p.rb + 255) / 256;
       dim3 grid((p.ra + 255) / 256, q.tiles_n * np, splits);
       wgrad_stream_kernel<><<<grid, 1024, 0, st>>>(q);
-      return launch_status();
-    }
-    case 7: {
-      GemmArgs q = p;
-      q.tiles_n = (p.rb + 255) / 256;
-      dim3 grid((p.ra + 255) / 256, q.tiles_n * np, splits);
-      wgrad_dma_kernel<><<<grid, 1024, 0, st>>>(q);
-      return launch_status();
-    }
-    case 5: {
-      GemmArgs q = p;
-      q.tiles_n = (p.rb + 255) / 256;
-      dim3 grid((p.ra + 255) / 256, q.tiles_n * np, splits);
-      wgrad_direct_kernel<5><<<grid, 1024, 0, st>>>(q);
       return launch_status();
     }
     default: return launch_tiles<128, 128, 2, 4, false, false>(p, np, splits, st);   // 1
@@ -1982,18 +1506,26 @@ int launch_wgrad(const GemmArgs& p, const WgradPlan& plan, hipStream_t st) {
 
 extern "C" int32_t gts_set_option(int32_t option, int32_t value) {
   switch (option) {
-    case GTS_OPT_GEMM_TILE: gts::g_fwd_variant = value; return GTS_OK;
-    case GTS_OPT_IGRAD_TILE: gts::g_igrad_variant = value; return GTS_OK;
+    case GTS_OPT_GEMM_TILE:      // the forms the library carries (the rejected ones live in tools/diag/gemm_rejected_forms.inc)
+      if (value != -1 && value != -2 && value != 1 && value != 3 && value != 5 && value != 8 && value != 10) return GTS_ERR_ARGKIND;
+      gts::g_fwd_variant = value;
+      return GTS_OK;
+    case GTS_OPT_IGRAD_TILE:
+      if (value != -1 && value != 1 && value != 3 && value != 5 && value != 8 && value != 10) return GTS_ERR_ARGKIND;
+      gts::g_igrad_variant = value;
+      return GTS_OK;
     case GTS_OPT_SPMM_ROWS_PER_WAVE: gts::g_spmm_seq = value; return GTS_OK;
     case GTS_OPT_SPMM_STREAMING: gts::g_spmm_nt = value; return GTS_OK;
     case GTS_OPT_PROJECT_STREAMING: gts::g_project_nt = value; return GTS_OK;
-    case GTS_OPT_WGRAD_TILE: gts::g_wgrad_variant = value; return GTS_OK;
+    case GTS_OPT_WGRAD_TILE:
+      if (value != -1 && value != 1 && value != 2 && value != 4 && value != 6) return GTS_ERR_ARGKIND;
+      gts::g_wgrad_variant = value;
+      return GTS_OK;
     case GTS_OPT_GEMM_SCHED: gts::g_gemm_sched = value; return GTS_OK;
     case GTS_OPT_CLUSTER_STREAMING: gts::g_cluster_nt = value; return GTS_OK;
     case GTS_OPT_PANEL_ROWS: gts::g_panel_rows = value; return GTS_OK;
     case GTS_OPT_GAT_WALK: gts::g_gat_walk = value; return GTS_OK;
     case GTS_OPT_GAT_CLUSTER_WAVES: gts::g_gat_cluster_waves = value; return GTS_OK;
-    case GTS_OPT_CLUSTER_KERNEL: gts::g_cluster_kernel = value; return GTS_OK;
     case GTS_OPT_CLUSTER_RING: gts::g_cluster_ring = value; return GTS_OK;
     case GTS_OPT_CLUSTER_PER_CU: gts::g_cluster_per_cu = value; return GTS_OK;
     case GTS_OPT_CLUSTER_CONSUMERS: gts::g_cluster_consumers = value; return GTS_OK;
@@ -2014,7 +1546,6 @@ extern "C" int32_t gts_get_option(int32_t option) {
     case GTS_OPT_PANEL_ROWS: return gts::g_panel_rows;
     case GTS_OPT_GAT_WALK: return gts::g_gat_walk;
     case GTS_OPT_GAT_CLUSTER_WAVES: return gts::g_gat_cluster_waves;
-    case GTS_OPT_CLUSTER_KERNEL: return gts::g_cluster_kernel;
     case GTS_OPT_CLUSTER_RING: return gts::g_cluster_ring;
     case GTS_OPT_CLUSTER_PER_CU: return gts::g_cluster_per_cu;
     case GTS_OPT_CLUSTER_CONSUMERS: return gts::g_cluster_consumers;

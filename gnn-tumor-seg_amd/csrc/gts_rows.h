@@ -105,7 +105,6 @@ inline int g_project_nt = 1;  // K12: non-temporal stores of the projected rows
 inline int g_spmm_nt = -1;   // streaming stores/loads of write-once / read-once rows; -1 = default
 inline int g_cluster_nt = -1;  // clustered K1 / K2 (gts_spmm_cluster.hip): bit 0 = streaming stores of out / gx; -1 = default
 inline int g_gat_walk = 1;           // K5-K8: 1 = head-major walk over the (node, head) rows, 0 = node-major
-inline int g_cluster_kernel = 0;     // 0 = persistent streaming form, 1 = one workgroup per unit, 2 = loader / consumer ring (A/B runs)
 inline int g_cluster_ring = 0;       // form 0: units the gathers run ahead (0 = automatic: 2 if it fits half a CU's LDS, else 1); form 2: ring slots
 inline int g_cluster_per_cu = 0;     // persistent workgroups per CU (0 = automatic)
 inline int g_gat_cluster_waves = 0;  // clustered GAT kernels: waves per workgroup (0 = default)

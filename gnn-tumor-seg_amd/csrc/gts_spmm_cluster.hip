@@ -24,10 +24,9 @@
 // Units of neighbouring clusters run on one XCD at the same time (halo rows meet in its L2).  The outputs land in
 // the rows the reference's node order gives them; the schedule only decides which workgroup produces which row.
 //
-// Two other forms are kept for A/B runs (GTS_OPT_CLUSTER_KERNEL): 1 = one workgroup per unit (record, barrier,
-// gather, barrier, reduce: 63 / 73 us where the persistent form is measured below); 2 = persistent workgroups
-// with dedicated loader waves feeding a ring of slots to consumer waves (81 - 90 / 108 - 120 us: one wave issuing
-// all gathers of a unit is slow, and the consumers are too few).
+// Two other launch forms were measured and rejected (one workgroup per unit: 63 - 71 / 73 us; loader waves feeding a ring
+// of slots to consumer waves: 81 - 90 / 108 - 120 us, against 64 - 67 us): their kernels live in
+// tools/diag/spmm_cluster_rejected_forms.inc, not in the library.
 #include <algorithm>
 #include <queue>
 #include <vector>
@@ -303,123 +302,6 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
   }
 }
 
-// ---- the persistent ring kernel -------------------------------------------------------------------------------
-// blockDim = 64 * (ring - 1 + consumers).  gridDim.x is a multiple of 8: the workgroups with blockIdx % 8 == x
-// (one XCD under round-robin placement; speed only) share the x-th eighth of the units and take them round-robin.
-template <bool BWD, int ARGB>
-__global__ __launch_bounds__(512) void spmm_cluster_ring_kernel(const ClusterArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  const int n_waves = blockDim.x / kWave;
-  const int n_loaders = a.ring - 1, n_consumers = n_waves - n_loaders;
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-  const long long n_units = 2LL * a.n_clusters;
-  const int lo = static_cast<int>(n_units * xcd / 8), hi = static_cast<int>(n_units * (xcd + 1) / 8);
-  const int n_my = lo + j < hi ? (hi - lo - j + per_xcd - 1) / per_xcd : 0;   // units lo + j + t * per_xcd, t < n_my
-  const int words = a.layout.words;
-
-  if (wave < n_loaders) {
-    // ------------------------------------------------------------------ loader: units t = wave, wave + n_loaders, ...
-    const BuiltinDma rt(a.table, a.table_bytes);
-    const BuiltinDma rw(a.winners, BWD ? a.winners_bytes : 0);
-    int32_t regs[kRecRegs];
-    int32_t src_a = 0, src_b = 0, src_c = 0, src_d = 0;   // neighbour ids 0-63 / 64-127 / 128-191 / 192-255, lane = id index % 64
-    auto fetch = [&](int t) {         // record of unit t -> registers (global loads, not waited for here)
-      const int32_t* r = a.rec + static_cast<size_t>((lo + j + t * per_xcd) >> 1) * words;
-#pragma unroll
-      for (int q = 0; q < kRecRegs; ++q) regs[q] = lane + 64 * q < words ? r[lane + 64 * q] : 0;
-      const int32_t* s = r + a.layout.srcs;
-      src_a = lane < a.max_srcs ? s[lane] : 0;
-      src_b = lane + 64 < a.max_srcs ? s[lane + 64] : 0;
-      src_c = lane + 128 < a.max_srcs ? s[lane + 128] : 0;
-      src_d = lane + 192 < a.max_srcs ? s[lane + 192] : 0;
-    };
-    auto issue = [&](int t) {         // registers -> the unit's slot, then its gathers
-      unsigned char* slot = lds + (t % a.ring) * a.slot_bytes;
-      int32_t* l_rec = reinterpret_cast<int32_t*>(slot);
-#pragma unroll
-      for (int q = 0; q < kRecRegs; ++q)
-        if (lane + 64 * q < words) l_rec[lane + 64 * q] = regs[q];
-      const int n_srcs = __builtin_amdgcn_readlane(regs[0], 1);
-      const int part = (lo + j + t * per_xcd) & 1;
-      const int half = lane >> 5;
-      gather_halves(rt, part, slot + a.image_off, n_srcs, 0, 2, [&](int i) {
-        const int32_t r = i < 64 ? src_a : i < 128 ? src_b : i < 192 ? src_c : src_d;   // i is wave-uniform and even
-        const int s0 = __builtin_amdgcn_readlane(r, i & 63), s1 = __builtin_amdgcn_readlane(r, (i & 63) + 1);
-        return half ? s1 : s0;
-      });
-      if constexpr (BWD) {
-        const int sub = lane >> 3;
-        gather_winner_halves(rw, part, slot + a.win_off, n_srcs, 0, 8, [&](int i) {
-          const int32_t r = i < 64 ? src_a : i < 128 ? src_b : i < 192 ? src_c : src_d;
-          // lane group g (8 lanes) wants id i + g: a cross-lane read of lane (i & 63) + g
-          return __builtin_amdgcn_ds_bpermute(4 * ((i & 63) + sub), r);
-        });
-      }
-    };
-    if (wave < n_my) {
-      fetch(wave);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      issue(wave);
-      if (wave + n_loaders < n_my) fetch(wave + n_loaders);
-    }
-    for (int it = 0; it < n_my; ++it) {
-      if (it % n_loaders == wave) {
-        barrier_all();                          // my gather of unit `it` has landed (and my next record has arrived)
-        const int t = it + n_loaders;           // the slot unit it - 1 used is free now
-        if (t < n_my) {
-          issue(t);
-          if (t + n_loaders < n_my) fetch(t + n_loaders);
-        }
-      } else {
-        barrier_lds();
-      }
-    }
-  } else {
-    // ------------------------------------------------------------------ consumer
-    const int me = wave - n_loaders;
-    for (int it = 0; it < n_my; ++it) {
-      barrier_lds();                            // unit `it` is complete in its slot
-      const unsigned char* slot = lds + (it % a.ring) * a.slot_bytes;
-      const int part = (lo + j + it * per_xcd) & 1;
-      if constexpr (BWD)
-        reduce_winner_rows(a, reinterpret_cast<const int32_t*>(slot), slot + a.image_off, slot + a.win_off, part, me, n_consumers);
-      else
-        reduce_max_rows<ARGB>(a, reinterpret_cast<const int32_t*>(slot), slot + a.image_off, part, me, n_consumers);
-    }
-  }
-}
-
-// ---- the simple form: one workgroup of 256 threads per unit ---------------------------------------------------
-template <bool BWD, int ARGB>
-__global__ __launch_bounds__(kBlock) void spmm_cluster_unit_kernel(const ClusterArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int u = xcd_contiguous_tile(blockIdx.x, gridDim.x);
-  const int part = u & 1;
-  const int32_t* r = a.rec + static_cast<size_t>(u >> 1) * a.layout.words;
-  int32_t* l_rec = reinterpret_cast<int32_t*>(lds);
-  for (int i = threadIdx.x; i < a.layout.words; i += kBlock) l_rec[i] = r[i];
-  __syncthreads();
-  const int n_srcs = l_rec[1];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  const int lane = threadIdx.x & (kWave - 1);
-  const int32_t* l_srcs = l_rec + a.layout.srcs;
-  const BuiltinDma rt(a.table, a.table_bytes);
-  gather_halves(rt, part, lds + a.image_off, n_srcs, 2 * wave, 2 * kWavesPerBlock, [&](int i) { return l_srcs[i + (lane >> 5)]; });
-  if constexpr (BWD) {
-    const BuiltinDma rw(a.winners, a.winners_bytes);
-    gather_winner_halves(rw, part, lds + a.win_off, n_srcs, 8 * wave, 8 * kWavesPerBlock,
-                         [&](int i) { return l_srcs[min(i + (lane >> 3), n_srcs - 1)]; });
-  }
-  __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
-  if constexpr (BWD)
-    reduce_winner_rows(a, l_rec, lds + a.image_off, lds + a.win_off, part, wave, kWavesPerBlock);
-  else
-    reduce_max_rows<ARGB>(a, l_rec, lds + a.image_off, part, wave, kWavesPerBlock);
-}
-
-
 struct LdsPlan {
   int slot_bytes, image_off, win_off;
 };
@@ -438,15 +320,9 @@ inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_
   const LdsPlan p = lds_plan(max_rows, a.max_srcs, loc_words, BWD);
   a.image_off = p.image_off, a.win_off = p.win_off, a.slot_bytes = p.slot_bytes;
   if (p.slot_bytes > kMaxLds) return GTS_ERR_SHAPE;
-  if (g_cluster_kernel == 1) {
-    static const bool once = (allow_big_lds(spmm_cluster_unit_kernel<BWD, ARGB>), true);
-    (void)once;
-    spmm_cluster_unit_kernel<BWD, ARGB><<<dim3(static_cast<unsigned>(2 * a.n_clusters)), kBlock, p.slot_bytes, st>>>(a);
-    return launch_status();
-  }
   const int64_t units = 2LL * a.n_clusters;
-  if (g_cluster_kernel != 2) {
-    // persistent streaming form: depth + 2 record slots + depth + 1 images per workgroup; two workgroups per CU.  Gathers run one
+  {
+    // the persistent streaming form: depth + 2 record slots + depth + 1 images per workgroup; two workgroups per CU.  Gathers run one
     // unit ahead; two units ahead (GTS_OPT_CLUSTER_RING = 2, where that fits) is kept for A/B runs: no gain measured
     const int64_t rec_slot = 1024LL * ((a.layout.words + 255) / 256), image = p.slot_bytes - p.image_off;
     const int depth = (g_cluster_ring == 2 && WHATIF == 0 && 4 * rec_slot + 3 * image <= kMaxLds) ? 2 : 1;
@@ -455,7 +331,11 @@ inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_
     a.ring = depth;
     const int waves = g_cluster_consumers > 0 ? std::min(16, g_cluster_consumers) : (BWD ? 12 : 16);
     if (a.max_srcs > 64 * waves) return GTS_ERR_SHAPE;
-    const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g_cluster_per_cu > 0 ? g_cluster_per_cu : 2, kMaxLds / wg_lds)));
+    // persistent workgroups per CU: two; three (where the LDS holds them) for a backward launch that gives a workgroup only a
+    // few units — C2: 8.8 units per workgroup, the reference's batches: 5 — where the pipeline's fill and drain weigh most
+    // (profiles/r04/tune_k2_small.log: 37.0 -> 35.2 us at 60 000 rows, 22.8 -> 22.0 at 35 000; nothing either way from 120 000 on)
+    const int auto_per_cu = (BWD && units <= 24LL * device_cus()) ? 3 : 2;
+    const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g_cluster_per_cu > 0 ? g_cluster_per_cu : auto_per_cu, kMaxLds / wg_lds)));
     int64_t grid = static_cast<int64_t>(device_cus()) * per_cu;
     grid = std::max<int64_t>(8, std::min(grid, (units + 7) / 8 * 8)) / 8 * 8;
     static const bool once = (allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF, 1>),
@@ -470,22 +350,6 @@ inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_
     spmm_cluster_stream_kernel<BWD, ARGB, WHATIF, 1><<<dim3(static_cast<unsigned>(grid)), waves * kWave, wg_lds, st>>>(a);
     return launch_status();
   }
-  // loader / consumer ring: as many slots as fit (at least 2: one loader), at most kMaxRing
-  int ring = g_cluster_ring > 0 ? g_cluster_ring : static_cast<int>(std::min<int64_t>(4, kMaxLds / p.slot_bytes));
-  ring = std::max(2, std::min(ring, kMaxRing));
-  if (static_cast<int64_t>(ring) * p.slot_bytes > kMaxLds) ring = static_cast<int>(kMaxLds / p.slot_bytes);
-  if (ring < 2) return GTS_ERR_SHAPE;
-  const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g_cluster_per_cu > 0 ? g_cluster_per_cu : 1,
-                                                                               kMaxLds / (static_cast<int64_t>(ring) * p.slot_bytes))));
-  a.ring = ring;
-  const int consumers = g_cluster_consumers > 0 ? g_cluster_consumers : 8 - (ring - 1);
-  const int waves = std::min(8, ring - 1 + std::max(1, consumers));
-  int64_t grid = static_cast<int64_t>(device_cus()) * per_cu;
-  grid = std::max<int64_t>(8, std::min(grid, (units + 7) / 8 * 8)) / 8 * 8;
-  static const bool once = (allow_big_lds(spmm_cluster_ring_kernel<BWD, ARGB>), true);
-  (void)once;
-  spmm_cluster_ring_kernel<BWD, ARGB><<<dim3(static_cast<unsigned>(grid)), waves * kWave, ring * p.slot_bytes, st>>>(a);
-  return launch_status();
 }
 
 }  // namespace

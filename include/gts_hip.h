@@ -435,11 +435,11 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
  * Process-wide tile selection of the K11 kernels (defaults are the tuned values; used by
  * tools/tune_gemm.py).  Returns GTS_ERR_ARGKIND for an unknown option. */
 #define GTS_OPT_GEMM_TILE 1  /* forward tile: -1 automatic, -2 automatic among the 32x32x2 tiles only (a row's result then does
-                                not depend on how many rows the call has: batched == per-sample, bit for bit), 1 = 128x256, 3 = 64x256, 5 = 256x128, 8 = 256x256 double-buffered, 9 = 240-row panels (16x16x4 MFMA) staged through LDS, 10 = the same panels with direct-to-fragment buffer loads (12 waves), 11 / 12 = 4 waves of 240x64, prefetch depth 1 / 2 */
-#define GTS_OPT_WGRAD_TILE 2 /* weight-gradient tile: -1 automatic, 1 = 128x128, 2 = 128x256, 4 = 256x256 double-buffered, 5 = 256x256 direct-to-fragment (no LDS), 7 = 256x256 with the operand tiles moved by LDS-DMA (buffer_load ... lds),
-                                6 = 7 with a main loop of MFMAs and LDS reads only (immediate-offset fragment reads, scalar-built DMA
-                                    descriptors, bias sums in one wave per SIMD): the automatic choice where 4 was (same bits as 4),
-                                8 / 9 = 256x256 with eight waves of 128x64 / 64x128 */
+                                not depend on how many rows the call has: batched == per-sample, bit for bit), 1 = 128x256, 3 = 64x256, 5 = 256x128, 8 = 256x256 double-buffered, 10 = 240 / 192 / 144-row panels (16x16x4 MFMA) with direct-to-fragment buffer loads (12 waves).  Other values: GTS_ERR_ARGKIND (the forms measured and rejected — panels staged through LDS, four waves of 240x64 — are built from tools/diag/, not shipped) */
+#define GTS_OPT_WGRAD_TILE 2 /* weight-gradient tile: -1 automatic, 1 = 128x128, 2 = 128x256, 4 = 256x256 double-buffered through registers and LDS,
+                                6 = the same tile moved by LDS-DMA with a main loop of MFMAs and LDS reads only (immediate-offset fragment
+                                    reads, scalar-built DMA descriptors, bias sums in one wave per SIMD): the automatic choice where 4 was
+                                    (same bits as 4).  Other values: GTS_ERR_ARGKIND (rejected tiles: tools/diag/gemm_rejected_forms.inc) */
 #define GTS_OPT_IGRAD_TILE 3 /* input-gradient tile: same numbering as the forward one (default 1) */
 #define GTS_OPT_PROJECT_STREAMING 6  /* K12: non-temporal stores of the projected rows (default 1) */
 #define GTS_OPT_SPMM_ROWS_PER_WAVE 4 /* K1-K4: rows one wave walks (0 = automatic) */
@@ -455,11 +455,9 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
 #define GTS_OPT_GAT_WALK 14          /* K5-K8: 1 = walk the (node, head) rows head-major (default), 0 = node-major */
 #define GTS_OPT_GAT_CLUSTER_WAVES 15 /* clustered GAT aggregation: waves per persistent workgroup (0 = default 12; up to 16) */
 #define GTS_OPT_PANEL_ROWS 13        /* K11 direct-to-fragment panels: rows per panel, 0 = automatic among 240 / 192 / 144 */
-#define GTS_OPT_CLUSTER_KERNEL 9     /* clustered K1 / K2: 0 = persistent streaming workgroups (default), 1 = one workgroup per unit,
-                                        2 = persistent workgroups with loader waves feeding a ring of slots to consumer waves */
-#define GTS_OPT_CLUSTER_RING 10      /* form 0: units the gathers run ahead of the reduction (0 = automatic, 1 .. 4); form 2: ring slots per workgroup */
-#define GTS_OPT_CLUSTER_PER_CU 11    /* forms 0 / 2: persistent workgroups per CU (0 = automatic) */
-#define GTS_OPT_CLUSTER_CONSUMERS 12 /* form 0: waves per workgroup (default 8); form 2: consumer waves (0 = automatic) */
+#define GTS_OPT_CLUSTER_RING 10      /* clustered K1 / K2: units the gathers run ahead of the reduction (0 = automatic: 1; 2 where the LDS holds it) */
+#define GTS_OPT_CLUSTER_PER_CU 11    /* clustered K1 / K2: persistent workgroups per CU (0 = automatic: 2, or 3 for short backward launches) */
+#define GTS_OPT_CLUSTER_CONSUMERS 12 /* clustered K1 / K2: waves per workgroup (0 = automatic: 16 forward, 12 backward) */
 int32_t gts_set_option(int32_t option, int32_t value);
 /* Current value of a knob (INT32_MIN for an unknown option): callers that change one temporarily put it back. */
 int32_t gts_get_option(int32_t option);

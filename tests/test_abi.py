@@ -32,6 +32,9 @@ def test_argument_errors_do_not_need_a_gpu(hip_lib):
     assert hip_lib.gts_gat_fwd_f32(one, one, one, one, one, 0.2, None, None, 0, one, one, 4, 0, 4, None) == -2
     assert hip_lib.gts_gat_fwd_f32(one, one, one, one, one, 0.2, None, None, 7, one, one, 4, 4, 4, None) == -3
     assert b"NULL" in hip_lib.gts_error_string(-1)
+    # tuning knobs take the kernel forms the library carries and nothing else (the rejected ones are built from tools/diag/)
+    assert hip_lib.gts_set_option(2, 7) == -3 and hip_lib.gts_set_option(1, 9) == -3 and hip_lib.gts_set_option(9, 1) == -3
+    assert hip_lib.gts_set_option(2, 6) == 0 and hip_lib.gts_set_option(2, -1) == 0
     # zero-sized problems are accepted without touching memory or the device
     assert hip_lib.gts_spmm_max_fwd_f32(one, one, one, one, None, 0, 1, 0, 4, None) == 0
 

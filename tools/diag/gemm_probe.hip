@@ -4,6 +4,7 @@
 // s_memrealtime counter and the shader-clock s_memtime counter (their ratio = in-kernel clock).
 // Built and driven by tools/diag/gemm_stamps.py.
 #include "../../gnn-tumor-seg_amd/csrc/gts_gemm.hip"
+#include "gemm_rejected_forms.inc"   // the kernel forms measured and rejected: built here, never shipped
 
 namespace gts {
 namespace {

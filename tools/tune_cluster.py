@@ -42,7 +42,7 @@ for b in [int(a) for a in sys.argv[1:]] or [4, 8, 32]:
           f"clusters={s_in.n_clusters}/{s_out.n_clusters} staged/row={s_in.staged_rows / n:.2f}/{s_out.staged_rows / n:.2f} "
           f"slot={s_in.lds_bytes(0)}/{s_out.lds_bytes(1)} B", flush=True)
     # (label, enabled, {option: value}): 9 = kernel form, 10 = ring slots, 11 = workgroups per CU, 12 = consumer waves
-    variants = [("plain", False, {}), ("unit-wg", True, {9: 1}), ("stream auto", True, {}),
+    variants = [("plain", False, {}), ("stream auto", True, {}),
                 ("stream depth 1", True, {10: 1}), ("stream depth 2", True, {10: 2}), ("stream depth 3", True, {10: 3}),
                 ("stream depth 2, 12 waves", True, {10: 2, 12: 12}), ("stream depth 2, 8 waves", True, {10: 2, 12: 8})]
     for label, enabled, options in variants:

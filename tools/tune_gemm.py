@@ -39,7 +39,7 @@ def timeit(fn, flops, reps=30):
 
 
 g1 = 2.0 * M * F * F
-VARIANTS = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8, 9, 1, 8, 9]
+VARIANTS = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8, 10, 1, 8, 10]
 
 
 def check(v):
