@@ -333,7 +333,8 @@ inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_
     if (a.max_srcs > 64 * waves) return GTS_ERR_SHAPE;
     // persistent workgroups per CU: two; three (where the LDS holds them) for a backward launch that gives a workgroup only a
     // few units — C2: 8.8 units per workgroup, the reference's batches: 5 — where the pipeline's fill and drain weigh most
-    // (profiles/r04/tune_k2_small.log: 37.0 -> 35.2 us at 60 000 rows, 22.8 -> 22.0 at 35 000; nothing either way from 120 000 on)
+    // (profiles/r04/tune_k2_small.log, operands from HBM: 37.0 -> 35.2 us at 60 000 rows, 22.8 -> 22.0 at 35 000; nothing either way from
+    // 120 000 rows on, and nothing in the training step, where the gradient rows were just written by the GEMM in front: 36.7 / 36.9 us)
     const int auto_per_cu = (BWD && units <= 24LL * device_cus()) ? 3 : 2;
     const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g_cluster_per_cu > 0 ? g_cluster_per_cu : auto_per_cu, kMaxLds / wg_lds)));
     int64_t grid = static_cast<int64_t>(device_cus()) * per_cu;
