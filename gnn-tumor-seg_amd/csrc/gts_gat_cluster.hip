@@ -233,6 +233,7 @@ struct GatClusterArgs {
   int side_floats, chunk_slots, side_pieces;
   int rec_bytes, side_slot_bytes, image_bytes;   // LDS: 3 record slots | 3 side slots | 3 vector slots of 1 KiB | 2 images
   int own_off;             // edge pass: byte offset of the own-row section inside an image
+  int group;               // clusters of an XCD's span walked together through all their (head, half) slices (see the kernel)
 };
 
 // the rows of one unit out of LDS: half a wave per row, 16 B per lane; acc += w_k * slice_k in slot order, one
@@ -389,11 +390,21 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
   const RawDma rs(a.side, a.side_bytes);
   const RawDma rv(a.vec, a.vec != nullptr ? a.vec_bytes : 0);
   const RawDma ro(MODE == 2 ? a.own : a.table, a.table_bytes);
+  // Unit order inside the span: groups of `a.group` consecutive clusters, a group walked through ALL its (head, half) slices
+  // before the next one — consecutive units (= what the XCD's workgroups hold at one time) are the same slice of the group's
+  // clusters, then the next slice of the same clusters.  A slice is 512 bytes of a 4 H KiB row: one slice of EVERY cluster of
+  // the span (group = span, round 3) puts the whole working set of the XCD's L2 into the sets 512 of every 4 096 bytes map
+  // to — an eighth of the cache at four heads — and halo slices left before the neighbouring cluster asked for them.
+  const unsigned group = static_cast<unsigned>(a.group > 0 && a.group < span ? a.group : span);
   auto unit = [&](int t, int* sub) {        // t-th unit of this workgroup: its cluster, and which (head, half) of it
     const unsigned i = static_cast<unsigned>(jw) + static_cast<unsigned>(t) * per_xcd;   // < 2^31 (host-checked)
-    const unsigned s = i / static_cast<unsigned>(span);
+    const unsigned per_group = group * static_cast<unsigned>(subs);
+    const unsigned gi = i / per_group, r = i - gi * per_group;
+    const unsigned first = gi * group;
+    const unsigned size = min(group, static_cast<unsigned>(span) - first);          // the last group of the span may be short
+    const unsigned s = r / size;
     *sub = static_cast<int>(s);
-    return clo + static_cast<int>(i - s * span);
+    return clo + static_cast<int>(first + (r - s * size));
   };
   auto fetch_record = [&](int t) {          // record, weights and epilogue vectors of unit t -> their slots, one LDS-DMA per piece and wave
     int sub;
@@ -510,6 +521,7 @@ int launch_gat_cluster(GatClusterArgs a, const GatPlan& p, hipStream_t st) {
   a.side_floats = p.side_floats, a.chunk_slots = p.chunk_slots, a.side_pieces = p.side_pieces;
   a.rec_bytes = p.rec_bytes, a.side_slot_bytes = p.side_slot_bytes, a.image_bytes = p.image_bytes;
   a.own_off = ((a.max_srcs + 1) & ~1) * kHalfBytes;
+  a.group = g_gat_cluster_group > 0 ? g_gat_cluster_group : 16;   // profiles/r04: source pass 152 -> 146 us, the other two passes unchanged
   const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({g_cluster_per_cu > 0 ? g_cluster_per_cu : 2, kMaxLds / p.wg_lds,
                                                                                static_cast<int64_t>(32 / p.waves)})));
   const int64_t units = 2LL * a.heads * a.n_clusters;
