@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
             for (int j = 0; j < CNT; ++j) {
               const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), k0 + j));
 #pragma unroll
-              for (int t = 0; t < VEC; ++t) acc[t] += a * val[j].v[t];
+              for (int t = 0; t < VEC; ++t) acc[t] = mad(a, val[j].v[t], acc[t]);
             }
           });
           gat_row_epilogue<VEC>(acc, out, bias, residual, act, r, h, dim, c, active);
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
             a[j] = expf(leaky(a[j] + er_v, slope) - m) / den;
             if (active && c == 0) attn[static_cast<size_t>(k + j) * heads + h] = a[j];
 #pragma unroll
-            for (int t = 0; t < VEC; ++t) acc[t] += a[j] * val[j].v[t];
+            for (int t = 0; t < VEC; ++t) acc[t] = mad(a[j], val[j].v[t], acc[t]);
           }
         }
       });
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(
 #pragma unroll
               for (int j = 0; j < CNT; ++j)
 #pragma unroll
-                for (int t = 0; t < VEC; ++t) part[j] += g.v[t] * f[j].v[t];
+                for (int t = 0; t < VEC; ++t) part[j] = mad(g.v[t], f[j].v[t], part[j]);
             }
           }
 #pragma unroll
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(
 #pragma unroll
             for (int j = 0; j < CNT; ++j)
 #pragma unroll
-              for (int t = 0; t < VEC; ++t) part[j] += g.v[t] * f[j].v[t];
+              for (int t = 0; t < VEC; ++t) part[j] = mad(g.v[t], f[j].v[t], part[j]);
           }
         }
 #pragma unroll
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(
           const Vec<VEC> g = Vec<VEC>::load(gout + static_cast<size_t>(r) * dim + c);
           const Vec<VEC> f = Vec<VEC>::load(ft + urow * dim + c);
 #pragma unroll
-          for (int t = 0; t < VEC; ++t) part += g.v[t] * f.v[t];
+          for (int t = 0; t < VEC; ++t) part = mad(g.v[t], f.v[t], part);
         }
       }
       const float ga = group_sum<LPR>(part);
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_kernel(
             for (int j = 0; j < CNT; ++j) {
               const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_l), k0 + j));
 #pragma unroll
-              for (int t = 0; t < VEC; ++t) acc[t] += a * val[j].v[t];
+              for (int t = 0; t < VEC; ++t) acc[t] = mad(a, val[j].v[t], acc[t]);
             }
           });
           Vec<VEC> o;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_kernel(
             const Vec<VEC> al = Vec<VEC>::load(attn_l + static_cast<size_t>(h) * dim + c);
             const Vec<VEC> ar = Vec<VEC>::load(attn_r + static_cast<size_t>(h) * dim + c);
 #pragma unroll
-            for (int t = 0; t < VEC; ++t) o.v[t] += gel_r * al.v[t] + ger_r * ar.v[t];
+            for (int t = 0; t < VEC; ++t) o.v[t] = mad(ger_r, ar.v[t], mad(gel_r, al.v[t], o.v[t]));
           }
           if (active) o.store(gft + static_cast<size_t>(r) * dim + c);
         });
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_kernel(
         for (int j = 0; j < CNT; ++j) {
           if (dst.valid(j)) {
 #pragma unroll
-            for (int t = 0; t < VEC; ++t) acc[t] += a[j] * val[j].v[t];
+            for (int t = 0; t < VEC; ++t) acc[t] = mad(a[j], val[j].v[t], acc[t]);
           }
         }
       });
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_kernel(
         const Vec<VEC> al = Vec<VEC>::load(attn_l + static_cast<size_t>(h) * dim + c);
         const Vec<VEC> ar = Vec<VEC>::load(attn_r + static_cast<size_t>(h) * dim + c);
 #pragma unroll
-        for (int t = 0; t < VEC; ++t) o.v[t] += gel_r * al.v[t] + ger_r * ar.v[t];
+        for (int t = 0; t < VEC; ++t) o.v[t] = mad(ger_r, ar.v[t], mad(gel_r, al.v[t], o.v[t]));
       }
       if (active) o.store(gft + static_cast<size_t>(r) * dim + c);
     });

@@ -16,6 +16,8 @@
 // (forward) and `gel * attn_l + ger * attn_r` (backward) ride in the row's epilogue out of a third small LDS-DMA.
 // Rows keep their place: the schedule only decides which workgroup computes which row.
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 #include "gts_cluster.h"
 
@@ -229,6 +231,8 @@ struct GatClusterArgs {
   const float* vec;        // forward: bias [H, 256] or null;  backward: attn_l | attn_r [2][H, 256] or null
   float* out;              // forward: out [N, H, 256];  backward: gft
   unsigned table_bytes, side_bytes, vec_bytes;
+  unsigned row_bytes, own_row_bytes;   // bytes between the rows of `table` / `own` (4 H KiB)
+  unsigned own_bytes;
   int heads, act, nt;
   int side_floats, chunk_slots, side_pieces;
   int rec_bytes, side_slot_bytes, image_bytes;   // LDS: 3 record slots | 3 side slots | 3 vector slots of 1 KiB | 2 images
@@ -236,9 +240,11 @@ struct GatClusterArgs {
   int group;               // clusters of an XCD's span walked together through all their (head, half) slices (see the kernel)
 };
 
-// the rows of one unit out of LDS: half a wave per row, 16 B per lane; acc += w_k * slice_k in slot order, one
-// straight-line body per exact edge count of an 8-edge chunk.  Returns the number of store instructions issued.
-template <bool BWD>
+// the rows of one unit out of LDS: half a wave per row, 16 B per lane; acc = w_k * slice_k + acc in slot order (`mad`), one
+// straight-line body per exact edge count of an 8-edge chunk.  The kernel is bound by the vector instructions it issues
+// (profiles/r04: without its gathers it takes 3 / 4 of its time), so the common pair of rows — equal degrees, one chunk — runs
+// a body without per-edge masks: the exact count is both rows' count.  Returns the number of store instructions issued.
+template <bool BWD, bool NOSTORE = false>   // NOSTORE: tools/diag what-if runs only
 __device__ __forceinline__ int reduce_wsum_rows(const GatClusterArgs& a, const int32_t* l_rec, const unsigned char* image,
                                                 const float* l_side, const float* l_vec, int sub, int first, int step) {
   const int lane = threadIdx.x & (kWave - 1), half = lane >> 5, hl = lane & 31;
@@ -252,26 +258,48 @@ __device__ __forceinline__ int reduce_wsum_rows(const GatClusterArgs& a, const i
     const bool have = j < n_rows;
     const uint32_t ri = have ? info[j] : 0u;
     const int c0 = ri & 0xFFFF, deg = ri >> 16;
-    const int deg_w = max(__builtin_amdgcn_readlane(deg, 0), __builtin_amdgcn_readlane(deg, 32));
+    const int deg_a = __builtin_amdgcn_readlane(deg, 0), deg_b = __builtin_amdgcn_readlane(deg, 32);
+    const int deg_w = max(deg_a, deg_b);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; 8 * c < deg_w; ++c) {
-      const int at = 8 * c < deg ? c0 + c : c0;                 // the shorter row of the pair re-reads its first chunk, masked below
-      const uint2 w = loc[at];
-      const float4 wa = *reinterpret_cast<const float4*>(l_side + at * 8), wb = *reinterpret_cast<const float4*>(l_side + at * 8 + 4);
-      const float wts[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-      for_count(min(8, deg_w - 8 * c), [&](auto cnt_c) {
-        constexpr int CNT = decltype(cnt_c)::value;
-        float4 val[CNT];
+    if (deg_a == deg_b && deg_w <= 8) {
+      if (deg_w > 0) {
+        const uint2 w = loc[c0];
+        const float4 wa = *reinterpret_cast<const float4*>(l_side + c0 * 8), wb = *reinterpret_cast<const float4*>(l_side + c0 * 8 + 4);
+        const float wts[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+        for_count(deg_w, [&](auto cnt_c) {
+          constexpr int CNT = decltype(cnt_c)::value;
+          float4 val[CNT];
 #pragma unroll
-        for (int q = 0; q < CNT; ++q) val[q] = *reinterpret_cast<const float4*>(mine + chunk_byte(w, q) * kHalfBytes);
+          for (int q = 0; q < CNT; ++q) val[q] = *reinterpret_cast<const float4*>(mine + chunk_byte(w, q) * kHalfBytes);
 #pragma unroll
-        for (int q = 0; q < CNT; ++q) {
-          const bool live = 8 * c + q < deg;
-          const float v4[4] = {val[q].x, val[q].y, val[q].z, val[q].w};
+          for (int q = 0; q < CNT; ++q) {
+            acc[0] = mad(wts[q], val[q].x, acc[0]);
+            acc[1] = mad(wts[q], val[q].y, acc[1]);
+            acc[2] = mad(wts[q], val[q].z, acc[2]);
+            acc[3] = mad(wts[q], val[q].w, acc[3]);
+          }
+        });
+      }
+    } else {
+      for (int c = 0; 8 * c < deg_w; ++c) {
+        const int at = 8 * c < deg ? c0 + c : c0;                 // the shorter row of the pair re-reads its first chunk, masked below
+        const uint2 w = loc[at];
+        const float4 wa = *reinterpret_cast<const float4*>(l_side + at * 8), wb = *reinterpret_cast<const float4*>(l_side + at * 8 + 4);
+        const float wts[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+        for_count(min(8, deg_w - 8 * c), [&](auto cnt_c) {
+          constexpr int CNT = decltype(cnt_c)::value;
+          float4 val[CNT];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t] = live ? acc[t] + wts[q] * v4[t] : acc[t];
-        }
-      });
+          for (int q = 0; q < CNT; ++q) val[q] = *reinterpret_cast<const float4*>(mine + chunk_byte(w, q) * kHalfBytes);
+#pragma unroll
+          for (int q = 0; q < CNT; ++q) {
+            const bool live = 8 * c + q < deg;
+            const float v4[4] = {val[q].x, val[q].y, val[q].z, val[q].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = live ? mad(wts[q], v4[t], acc[t]) : acc[t];
+          }
+        });
+      }
     }
     Vec<4> o{{acc[0], acc[1], acc[2], acc[3]}};
     if constexpr (BWD) {
@@ -280,7 +308,7 @@ __device__ __forceinline__ int reduce_wsum_rows(const GatClusterArgs& a, const i
         const float4 al = *reinterpret_cast<const float4*>(l_vec + hl * 4), ar = *reinterpret_cast<const float4*>(l_vec + 128 + hl * 4);
         const float al4[4] = {al.x, al.y, al.z, al.w}, ar4[4] = {ar.x, ar.y, ar.z, ar.w};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) o.v[t] += sc.x * al4[t] + sc.y * ar4[t];
+        for (int t = 0; t < 4; ++t) o.v[t] = mad(sc.y, ar4[t], mad(sc.x, al4[t], o.v[t]));
       }
     } else {
       if (a.vec != nullptr) {
@@ -295,12 +323,14 @@ __device__ __forceinline__ int reduce_wsum_rows(const GatClusterArgs& a, const i
         for (int t = 0; t < 4; ++t) o.v[t] = o.v[t] > 0.0f ? o.v[t] : e[t];
       }
     }
-    if (have) {   // streamed out (GTS_OPT_CLUSTER_STREAMING, default on): the rows just written do not push the halo slices out of the XCD's L2
+    if constexpr (NOSTORE) {
+      if (o.v[0] == 123.456f) a.out[0] = o.v[1] + o.v[2] + o.v[3];
+    } else if (have) {   // streamed out (GTS_OPT_CLUSTER_STREAMING, default on): the rows just written do not push the halo slices out of the XCD's L2
       float* dst = a.out + (static_cast<size_t>(l_rec[a.layout.rows + j]) * a.heads * kF + sub * (kF / 2) + hl * 4);
       if (a.nt) o.store_nt(dst); else o.store(dst);
     }
   }
-  return trips;
+  return NOSTORE ? 0 : trips;
 }
 
 // Edge pass of the backward (K8, step 1): ga_k = <g_pre[v, h, :], ft[src_k, h, :]> for every in-edge.  A unit holds one column
@@ -334,10 +364,10 @@ __device__ __forceinline__ int reduce_edge_rows(const GatClusterArgs& a, const i
         for (int q = 0; q < CNT; ++q) val[q] = *reinterpret_cast<const float4*>(mine + chunk_byte(w, q) * kHalfBytes);
 #pragma unroll
         for (int q = 0; q < CNT; ++q) {
-          part[q] += g.x * val[q].x;
-          part[q] += g.y * val[q].y;
-          part[q] += g.z * val[q].z;
-          part[q] += g.w * val[q].w;
+          part[q] = mad(g.x, val[q].x, part[q]);
+          part[q] = mad(g.y, val[q].y, part[q]);
+          part[q] = mad(g.z, val[q].z, part[q]);
+          part[q] = mad(g.w, val[q].w, part[q]);
         }
       });
       // The butterfly 16, 8, 4, 2, 1 of all eight sums at once: at each of the first three steps a lane keeps the half of
@@ -366,9 +396,17 @@ __device__ __forceinline__ int reduce_edge_rows(const GatClusterArgs& a, const i
 // column half of neighbouring clusters, whose halo slices meet in its L2.
 // MINW = 8: up to 16 waves per workgroup at <= 64 registers; 6: up to 12 waves at <= 80 (two workgroups per CU either way)
 // MODE 0: forward aggregation;  1: source pass of the backward;  2: edge pass of the backward (half dot products)
-template <int MODE, int MINW>
+// DEPTH: units the gathers run ahead of the reduction (DEPTH + 1 images).  A unit's reduction is short beside the round trip
+// of its gathers, so with one unit ahead a workgroup spends most of an iteration waiting for the LAST of ~35 KB to land and the
+// kernel's rate is (bytes in flight) / (loaded latency), whatever the L2 hits (profiles/r04: the time does not move with the
+// bytes fetched); deeper images keep more of the LDS in flight.  Records run max(1, DEPTH - 1) units in front of the gathers.
+// WHATIF (tools/diag only): 1 = no neighbour gathers, 2 = no reduction and no stores, 3 = reduction without stores
+template <int MODE, int MINW, int DEPTH = 1, int WHATIF = 0>
 __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const GatClusterArgs a) {
   constexpr bool BWD = MODE == 1;
+  constexpr int AHEAD = DEPTH > 1 ? DEPTH - 1 : 1;   // records are fetched this many units in front of their gathers
+  constexpr int R = DEPTH + AHEAD + 1;               // record / weight / vector slots
+  constexpr int IMAGES = DEPTH + 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -382,112 +420,195 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
   if (n_my == 0) return;
   const int words = a.layout.words;
   const int rec_pieces = a.rec_bytes / 1024;
-  unsigned char* side_slots = lds + 3 * a.rec_bytes;
-  unsigned char* vec_slots = side_slots + 3 * a.side_slot_bytes;
-  unsigned char* images = MODE == 2 ? lds + 3 * a.rec_bytes : vec_slots + 3 * 1024;   // the edge pass keeps no weight / vector slots
+  unsigned char* side_slots = lds + R * a.rec_bytes;
+  unsigned char* vec_slots = side_slots + R * a.side_slot_bytes;
+  unsigned char* images = MODE == 2 ? lds + R * a.rec_bytes : vec_slots + R * 1024;   // the edge pass keeps no weight / vector slots
   const RawDma rr(a.rec, static_cast<unsigned>(a.n_clusters) * words * 4u);
   const RawDma rt(a.table, a.table_bytes);
   const RawDma rs(a.side, a.side_bytes);
   const RawDma rv(a.vec, a.vec != nullptr ? a.vec_bytes : 0);
-  const RawDma ro(MODE == 2 ? a.own : a.table, a.table_bytes);
+  const RawDma ro(MODE == 2 ? a.own : a.table, MODE == 2 ? a.own_bytes : a.table_bytes);
   // Unit order inside the span: groups of `a.group` consecutive clusters, a group walked through ALL its (head, half) slices
   // before the next one — consecutive units (= what the XCD's workgroups hold at one time) are the same slice of the group's
-  // clusters, then the next slice of the same clusters.  A slice is 512 bytes of a 4 H KiB row: one slice of EVERY cluster of
-  // the span (group = span, round 3) puts the whole working set of the XCD's L2 into the sets 512 of every 4 096 bytes map
-  // to — an eighth of the cache at four heads — and halo slices left before the neighbouring cluster asked for them.
+  // clusters, then the next slice of the same clusters.
   const unsigned group = static_cast<unsigned>(a.group > 0 && a.group < span ? a.group : span);
-  auto unit = [&](int t, int* sub) {        // t-th unit of this workgroup: its cluster, and which (head, half) of it
-    const unsigned i = static_cast<unsigned>(jw) + static_cast<unsigned>(t) * per_xcd;   // < 2^31 (host-checked)
+  // The walk is kept as scalar state and advanced by per_xcd units at a time (a few scalar operations: the two integer divisions
+  // of the closed form, taken three times per iteration, were a fifth of the kernel's time — profiles/r04): `at` = the unit
+  // fetch_record takes next, (first, size) its group, s its slice, c its cluster inside the group.
+  unsigned w_first, w_size, w_s, w_c;
+  {
+    const unsigned i = static_cast<unsigned>(jw);                                  // this workgroup's first unit: the closed form, once
     const unsigned per_group = group * static_cast<unsigned>(subs);
     const unsigned gi = i / per_group, r = i - gi * per_group;
-    const unsigned first = gi * group;
-    const unsigned size = min(group, static_cast<unsigned>(span) - first);          // the last group of the span may be short
-    const unsigned s = r / size;
-    *sub = static_cast<int>(s);
-    return clo + static_cast<int>(first + (r - s * size));
+    w_first = gi * group;
+    w_size = min(group, static_cast<unsigned>(span) - w_first);
+    w_s = r / w_size;
+    w_c = r - w_s * w_size;
+  }
+  auto advance = [&]() {                     // per_xcd units on; past the span's end the state is never used (size kept >= 1)
+    w_c += static_cast<unsigned>(per_xcd);
+    while (w_c >= w_size) {
+      w_c -= w_size;
+      if (++w_s == static_cast<unsigned>(subs)) {
+        w_s = 0;
+        w_first += group;
+        w_size = w_first < static_cast<unsigned>(span) ? min(group, static_cast<unsigned>(span) - w_first) : 0x40000000u;
+      }
+    }
   };
-  auto fetch_record = [&](int t) {          // record, weights and epilogue vectors of unit t -> their slots, one LDS-DMA per piece and wave
-    int sub;
-    const unsigned cluster = static_cast<unsigned>(unit(t, &sub));
-    const int slot = t % 3;
+  // (cluster, sub) of the units in the pipeline: [0] = the one fetch_record took last ... [PIPE - 1] = the one being reduced
+  constexpr int PIPE = DEPTH + AHEAD + 1;
+  int u_cluster[PIPE], u_sub[PIPE];
+#pragma unroll
+  for (int q = 0; q < PIPE; ++q) u_cluster[q] = clo, u_sub[q] = 0;
+  auto next_unit = [&]() {                   // shift the pipeline, enter the walk's unit at [0], advance the walk
+#pragma unroll
+    for (int q = PIPE - 1; q > 0; --q) u_cluster[q] = u_cluster[q - 1], u_sub[q] = u_sub[q - 1];
+    u_cluster[0] = clo + static_cast<int>(w_first + w_c), u_sub[0] = static_cast<int>(w_s);
+    advance();
+  };
+  // record, weights and epilogue vectors of unit t -> their slots, one LDS-DMA per piece and wave.  Returns this wave's count
+  auto fetch_record = [&](int t, int cluster_id, int sub) {
+    const unsigned cluster = static_cast<unsigned>(cluster_id);
+    const int slot = t % R;
     if (wave < rec_pieces) {
       const int word = 256 * wave + 4 * lane;
       rr(lds + slot * a.rec_bytes + 1024 * wave, word < words ? (cluster * static_cast<unsigned>(words) + word) * 4u : 0xFFFFFFF0u);
+      return 1;
     } else if (MODE == 2) {
       // the edge pass fetches nothing but the record
     } else if (wave < rec_pieces + a.side_pieces) {
       const int p = wave - rec_pieces, word = 256 * p + 4 * lane;
       const unsigned base = (cluster * static_cast<unsigned>(a.heads) + static_cast<unsigned>(sub >> 1)) * static_cast<unsigned>(a.side_floats);
       rs(side_slots + slot * a.side_slot_bytes + 1024 * p, word < a.side_floats ? (base + word) * 4u : 0xFFFFFFF0u);
+      return 1;
     } else if (wave == rec_pieces + a.side_pieces && a.vec != nullptr) {
       // 128 floats of this (head, half) from each vector: lanes 0-31 the first (bias / attn_l), lanes 32-63 the second (attn_r)
       const unsigned first = static_cast<unsigned>(sub) * 128u + (lane & 31) * 4u;
       const unsigned off = (lane < 32 ? first : BWD ? static_cast<unsigned>(a.heads) * kF + first : 0x3FFFFFFCu) * 4u;
       rv(vec_slots + slot * 1024, off);
+      return 1;
     }
+    return 0;
   };
-  auto issue_gathers = [&](int t) {         // this wave's share of unit t's gathers; its record is in LDS
-    int sub;
-    unit(t, &sub);
-    const int32_t* l_rec = reinterpret_cast<const int32_t*>(lds + (t % 3) * a.rec_bytes);
-    unsigned char* image = images + (t & 1) * a.image_bytes;
+  auto issue_gathers = [&](int t, int sub) {   // this wave's share of unit t's gathers; its record is in LDS.  Returns their count
+    const int32_t* l_rec = reinterpret_cast<const int32_t*>(lds + (t % R) * a.rec_bytes);
+    unsigned char* image = images + (t % IMAGES) * a.image_bytes;
     const int n_srcs = l_rec[1];
     // lane l keeps the id of row 2 (wave + n_waves (l / 2)) + l % 2: every row pair this wave fetches, one LDS read
     const int last = pad4(a.max_srcs) - 1;
     const int32_t ids = l_rec[a.layout.srcs + min(2 * (wave + n_waves * (lane >> 1)) + (lane & 1), last)];
-    const unsigned row_bytes = static_cast<unsigned>(a.heads) * (kF * 4u);
+    const unsigned row_bytes = a.row_bytes;
     const unsigned col = static_cast<unsigned>(sub) * kHalfBytes + (lane & 31) * 16u;
     int k = 0;
-    for (int i = 2 * wave; i < n_srcs; i += 2 * n_waves, ++k) {
-      const int s0 = __builtin_amdgcn_readlane(ids, 2 * k), s1 = __builtin_amdgcn_readlane(ids, 2 * k + 1);
-      rt(image + i * kHalfBytes, static_cast<unsigned>(lane < 32 ? s0 : s1) * row_bytes + col);
-    }
-    if constexpr (MODE == 2) {              // ... and of its rows' own gradient slices, the same way out of the other table
-      const int n_rows = l_rec[0];
-      const int32_t own_ids = l_rec[a.layout.rows + min(2 * (wave + n_waves * (lane >> 1)) + (lane & 1), n_rows - 1)];
-      int k2 = 0;
-      for (int i = 2 * wave; i < n_rows; i += 2 * n_waves, ++k2) {
-        const int s0 = __builtin_amdgcn_readlane(own_ids, 2 * k2), s1 = __builtin_amdgcn_readlane(own_ids, 2 * k2 + 1);
-        ro(image + a.own_off + i * kHalfBytes, static_cast<unsigned>(lane < 32 ? s0 : s1) * row_bytes + col);
+    if constexpr (WHATIF != 1) {
+      for (int i = 2 * wave; i < n_srcs; i += 2 * n_waves, ++k) {
+        const int s0 = __builtin_amdgcn_readlane(ids, 2 * k), s1 = __builtin_amdgcn_readlane(ids, 2 * k + 1);
+        rt(image + i * kHalfBytes, static_cast<unsigned>(lane < 32 ? s0 : s1) * row_bytes + col);
       }
     }
+    int k2 = 0;
+    if constexpr (MODE == 2 && WHATIF != 1) {   // ... and of its rows' own gradient slices, the same way out of the other table
+      const int n_rows = l_rec[0];
+      const int32_t own_ids = l_rec[a.layout.rows + min(2 * (wave + n_waves * (lane >> 1)) + (lane & 1), n_rows - 1)];
+      for (int i = 2 * wave; i < n_rows; i += 2 * n_waves, ++k2) {
+        const int s0 = __builtin_amdgcn_readlane(own_ids, 2 * k2), s1 = __builtin_amdgcn_readlane(own_ids, 2 * k2 + 1);
+        ro(image + a.own_off + i * kHalfBytes, static_cast<unsigned>(lane < 32 ? s0 : s1) * a.own_row_bytes + col);
+      }
+    }
+    return k + k2;
   };
 
-  // Per iteration a wave issues, in this order: [record / weights / vectors of unit it + 2] [gathers of unit it + 1] [stores
-  // of unit it].  At the top of iteration `it` everything but the stores of the iteration before must have landed
-  // (vector-memory operations retire in order).
-  fetch_record(0);
-  if (n_my > 1) fetch_record(1);
+  // Iteration `it` issues, in this order: [record / weights / vectors of unit it + DEPTH + AHEAD] [gathers of unit it + DEPTH]
+  // [stores of unit it].  At its top the gathers of unit `it` and the record of unit it + DEPTH must have landed; vector-memory
+  // operations retire in order, and the record of unit it + DEPTH was issued in front of the gathers of unit it + 1 (AHEAD =
+  // DEPTH - 1; for DEPTH 1 in front of those of unit `it`), so everything YOUNGER than that record fetch may stay in flight:
+  // the gathers of units it + 1 .. it + DEPTH - 1, the stores of the last DEPTH - 1 iterations (for DEPTH 1: of the last
+  // one), and the record fetches of the last DEPTH - 2 iterations.
+  constexpr int HIST = DEPTH > 1 ? DEPTH - 1 : 1;
+  int g_hist[HIST], s_hist[HIST], r_hist[HIST];   // [0] = youngest; wave-uniform counts of this wave's operations
+#pragma unroll
+  for (int q = 0; q < HIST; ++q) g_hist[q] = s_hist[q] = r_hist[q] = 0;
+#pragma unroll
+  for (int t = 0; t < DEPTH + AHEAD; ++t) {   // afterwards u_*[DEPTH + AHEAD - 1 - t] is unit t
+    next_unit();
+    if (t < n_my) fetch_record(t, u_cluster[0], u_sub[0]);
+  }
   barrier_all();
-  issue_gathers(0);
-  int stores = 0;
+#pragma unroll
+  for (int t = 0; t < DEPTH; ++t) {
+    const int cnt = t < n_my ? issue_gathers(t, u_sub[DEPTH + AHEAD - 1 - t]) : 0;
+    if (t >= 1) {                              // the gathers of units 1 .. DEPTH - 1 stay in flight past the first wait
+#pragma unroll
+      for (int q = HIST - 1; q > 0; --q) g_hist[q] = g_hist[q - 1];
+      g_hist[0] = cnt;
+    }
+  }
+  // WHATIF == 9 (tools/diag only): shader-clock stamps of wave 0 around the phases of an iteration, summed per workgroup into
+  // `out` (then a buffer of 8 x uint64 per workgroup, no rows are stored): wait for gathers | barrier | issue | reduce
+  unsigned long long phase[4] = {0, 0, 0, 0}, stamp = 0;
+  auto lap = [&](int which) {
+    if constexpr (WHATIF == 9) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      phase[which] += now - stamp;
+      stamp = now;
+    }
+  };
+  if constexpr (WHATIF == 9) stamp = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < n_my; ++it) {
-    wait_vm_all_but(stores);
-    barrier_lds();                          // ... and everyone else's; the other image and the oldest slots are free
-    if (it + 2 < n_my) fetch_record(it + 2);
-    if (it + 1 < n_my) issue_gathers(it + 1);
-    int sub;
-    unit(it, &sub);
-    const int slot = it % 3;
-    if constexpr (MODE == 2) {
-      const int cluster = unit(it, &sub);
+    int keep = 0;
+    if constexpr (DEPTH == 1) {
+      keep = s_hist[0];
+    } else {
+#pragma unroll
+      for (int q = 0; q < DEPTH - 1; ++q) keep += g_hist[q] + s_hist[q];
+#pragma unroll
+      for (int q = 0; q < DEPTH - 2; ++q) keep += r_hist[q];
+    }
+    wait_vm_all_but(keep);
+    lap(0);
+    barrier_lds();                          // ... and everyone else's; the oldest image and the oldest slots are free
+    lap(1);
+    next_unit();                            // u_*[0] = unit it + DEPTH + AHEAD, [AHEAD] = unit it + DEPTH, [PIPE - 1] = unit it
+    const int recs = it + DEPTH + AHEAD < n_my ? fetch_record(it + DEPTH + AHEAD, u_cluster[0], u_sub[0]) : 0;
+    const int gathers = it + DEPTH < n_my ? issue_gathers(it + DEPTH, u_sub[AHEAD]) : 0;
+    lap(2);
+    const int sub = u_sub[PIPE - 1], cluster = u_cluster[PIPE - 1];
+    const int slot = it % R;
+    int stores = 0;
+    if constexpr (WHATIF == 2) {
+      (void)cluster;
+    } else if constexpr (MODE == 2) {
       // partial dot products of this (cluster, head) for column half `sub & 1`
       float* block = a.out + (static_cast<size_t>(sub & 1) * a.n_clusters * a.heads + static_cast<size_t>(cluster) * a.heads + (sub >> 1)) *
                                  (a.chunk_slots * 8);
-      stores = reduce_edge_rows(a, reinterpret_cast<const int32_t*>(lds + slot * a.rec_bytes), images + (it & 1) * a.image_bytes, block,
+      stores = reduce_edge_rows(a, reinterpret_cast<const int32_t*>(lds + slot * a.rec_bytes), images + (it % IMAGES) * a.image_bytes, block,
                                 wave, n_waves);
     } else {
-      stores = reduce_wsum_rows<BWD>(a, reinterpret_cast<const int32_t*>(lds + slot * a.rec_bytes), images + (it & 1) * a.image_bytes,
-                                     reinterpret_cast<const float*>(side_slots + slot * a.side_slot_bytes),
-                                     reinterpret_cast<const float*>(vec_slots + slot * 1024), sub, wave, n_waves);
+      stores = reduce_wsum_rows<BWD, WHATIF == 3 || WHATIF == 9>(a, reinterpret_cast<const int32_t*>(lds + slot * a.rec_bytes),
+                                                   images + (it % IMAGES) * a.image_bytes,
+                                                   reinterpret_cast<const float*>(side_slots + slot * a.side_slot_bytes),
+                                                   reinterpret_cast<const float*>(vec_slots + slot * 1024), sub, wave, n_waves);
+    }
+#pragma unroll
+    for (int q = HIST - 1; q > 0; --q) g_hist[q] = g_hist[q - 1], s_hist[q] = s_hist[q - 1], r_hist[q] = r_hist[q - 1];
+    g_hist[0] = gathers, s_hist[0] = stores, r_hist[0] = recs;
+    lap(3);
+  }
+  if constexpr (WHATIF == 9) {
+    if (threadIdx.x == 0) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.out) + 8 * static_cast<size_t>(blockIdx.x);
+      for (int q = 0; q < 4; ++q) dbg[q] = phase[q];
+      dbg[4] = static_cast<unsigned long long>(n_my);
     }
   }
 }
 
 struct GatPlan {
-  int chunk_slots, side_floats, side_pieces, rec_bytes, side_slot_bytes, image_bytes, waves;
+  int chunk_slots, side_floats, side_pieces, rec_bytes, side_slot_bytes, image_bytes, waves, depth;
   int64_t wg_lds;
 };
+// depth: units the gathers run ahead (GTS_OPT_GAT_CLUSTER_DEPTH; the deepest the LDS holds, at least 1)
 inline GatPlan gat_plan(int max_rows, int max_srcs, int loc_words, bool tagged, bool bwd, bool edge = false) {
   GatPlan p;
   p.chunk_slots = loc_words / 2;
@@ -497,7 +618,11 @@ inline GatPlan gat_plan(int max_rows, int max_srcs, int loc_words, bool tagged, 
   p.side_slot_bytes = 1024 * p.side_pieces;
   p.image_bytes = (((max_srcs + 1) & ~1) + (edge ? (max_rows + 1) & ~1 : 0)) * kHalfBytes;   // edge pass: the rows' own slices behind the neighbours'
   p.waves = g_gat_cluster_waves > 0 ? std::max(4, std::min(16, g_gat_cluster_waves)) : 12;
-  p.wg_lds = 3LL * p.rec_bytes + (edge ? 0 : 3LL * p.side_slot_bytes + 3 * 1024) + 2LL * p.image_bytes;
+  for (p.depth = std::max(1, std::min(3, g_gat_cluster_depth > 0 ? g_gat_cluster_depth : 1));; --p.depth) {
+    const int64_t slots = p.depth + std::max(1, p.depth - 1) + 1;
+    p.wg_lds = slots * p.rec_bytes + (edge ? 0 : slots * (p.side_slot_bytes + 1024)) + (p.depth + 1LL) * p.image_bytes;
+    if (p.wg_lds <= kMaxLds || p.depth == 1) break;
+  }
   return p;
 }
 
@@ -516,7 +641,7 @@ inline bool bad_gat_cluster(int64_t n_clusters, int32_t max_rows, int32_t max_sr
   return false;
 }
 
-template <int MODE>
+template <int MODE, int WHATIF = 0>
 int launch_gat_cluster(GatClusterArgs a, const GatPlan& p, hipStream_t st) {
   a.side_floats = p.side_floats, a.chunk_slots = p.chunk_slots, a.side_pieces = p.side_pieces;
   a.rec_bytes = p.rec_bytes, a.side_slot_bytes = p.side_slot_bytes, a.image_bytes = p.image_bytes;
@@ -527,11 +652,25 @@ int launch_gat_cluster(GatClusterArgs a, const GatPlan& p, hipStream_t st) {
   const int64_t units = 2LL * a.heads * a.n_clusters;
   int64_t grid = static_cast<int64_t>(device_cus()) * per_cu;
   grid = std::max<int64_t>(8, std::min(grid, (units + 7) / 8 * 8)) / 8 * 8;
-  static const bool once = (allow_big_lds(gat_cluster_stream_kernel<MODE, 6>), allow_big_lds(gat_cluster_stream_kernel<MODE, 8>), true);
-  (void)once;
-  if (p.waves > 12) gat_cluster_stream_kernel<MODE, 8><<<dim3(static_cast<unsigned>(grid)), p.waves * kWave, p.wg_lds, st>>>(a);
-  else gat_cluster_stream_kernel<MODE, 6><<<dim3(static_cast<unsigned>(grid)), p.waves * kWave, p.wg_lds, st>>>(a);
-  return launch_status();
+  auto go = [&](auto kernel) {
+    static std::mutex guard;               // the LDS attribute once per kernel, not per launch
+    static std::vector<const void*> allowed;
+    {
+      std::lock_guard<std::mutex> lock(guard);
+      const void* id = reinterpret_cast<const void*>(kernel);
+      if (std::find(allowed.begin(), allowed.end(), id) == allowed.end()) allow_big_lds(kernel), allowed.push_back(id);
+    }
+    kernel<<<dim3(static_cast<unsigned>(grid)), p.waves * kWave, p.wg_lds, st>>>(a);
+    return launch_status();
+  };
+  if (p.waves > 12) {
+    if (p.depth == 3) return go(gat_cluster_stream_kernel<MODE, 8, 3, WHATIF>);
+    if (p.depth == 2) return go(gat_cluster_stream_kernel<MODE, 8, 2, WHATIF>);
+    return go(gat_cluster_stream_kernel<MODE, 8, 1, WHATIF>);
+  }
+  if (p.depth == 3) return go(gat_cluster_stream_kernel<MODE, 6, 3, WHATIF>);
+  if (p.depth == 2) return go(gat_cluster_stream_kernel<MODE, 6, 2, WHATIF>);
+  return go(gat_cluster_stream_kernel<MODE, 6, 1, WHATIF>);
 }
 
 template <typename Launch>
@@ -605,7 +744,8 @@ extern "C" int32_t gts_gat_fwd_cluster_f32(const int32_t* indptr, const int32_t*
   GatClusterArgs a{};
   a.rec = rec, a.layout = lay, a.n_clusters = static_cast<int>(n_clusters), a.max_srcs = max_srcs;
   a.table = ft, a.side = workspace, a.vec = bias, a.out = out;
-  a.table_bytes = static_cast<unsigned>(n * heads * kF * 4);
+  a.row_bytes = static_cast<unsigned>(heads * kF * 4);
+  a.table_bytes = static_cast<unsigned>(n * a.row_bytes);
   a.side_bytes = static_cast<unsigned>(n_clusters * heads * p.side_floats * 4);
   a.vec_bytes = static_cast<unsigned>(heads * kF * 4);
   a.heads = nh, a.act = activation, a.nt = g_cluster_nt < 0 ? 1 : (g_cluster_nt & 1);
@@ -640,7 +780,8 @@ extern "C" int32_t gts_gat_bwd_src_cluster_f32(const int32_t* t_indptr, const in
   GatClusterArgs a{};
   a.rec = rec, a.layout = lay, a.n_clusters = static_cast<int>(n_clusters), a.max_srcs = max_srcs;
   a.table = gout, a.side = workspace, a.vec = attn_lr, a.out = gft;
-  a.table_bytes = static_cast<unsigned>(n * heads * kF * 4);
+  a.row_bytes = static_cast<unsigned>(heads * kF * 4);
+  a.table_bytes = static_cast<unsigned>(n * a.row_bytes);
   a.side_bytes = static_cast<unsigned>(n_clusters * heads * p.side_floats * 4);
   a.vec_bytes = static_cast<unsigned>(2 * heads * kF * 4);
   a.heads = nh, a.act = 0, a.nt = g_cluster_nt < 0 ? 1 : (g_cluster_nt & 1);
@@ -665,7 +806,8 @@ extern "C" int32_t gts_gat_bwd_edge_cluster_f32(const int32_t* indptr, const int
   GatClusterArgs a{};
   a.rec = rec, a.layout = lay, a.n_clusters = static_cast<int>(n_clusters), a.max_srcs = max_srcs;
   a.table = ft, a.own = gout, a.out = workspace;
-  a.table_bytes = static_cast<unsigned>(n * heads * kF * 4);
+  a.row_bytes = a.own_row_bytes = static_cast<unsigned>(heads * kF * 4);
+  a.table_bytes = static_cast<unsigned>(n * a.row_bytes), a.own_bytes = static_cast<unsigned>(n * a.own_row_bytes);
   a.heads = static_cast<int>(heads);
   int rc = launch_gat_cluster<2>(a, p, st);
   if (rc != GTS_OK) return rc;

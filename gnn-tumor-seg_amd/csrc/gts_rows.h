@@ -9,6 +9,13 @@ namespace gts {
 
 constexpr int kUnroll = 8;
 
+// w * v + acc in ONE instruction and one rounding (v_fma_f32; the library is built with -ffp-contract=off, so this is the only
+// place products and sums fuse).  GATConv's weighted sums and dot products (K5 - K8, plain and clustered kernels alike, so the
+// two stay bit-identical): the clustered kernels are bound by the vector instructions they issue, and a separate multiply and
+// add per element were half of a neighbour's cost (profiles/r04).  DGL's own CPU kernel leaves the contraction to its compiler;
+// the oracle comparison holds at the stated tolerance either way (one rounding instead of two per term).
+__device__ __forceinline__ float mad(float w, float v, float acc) { return __builtin_fmaf(w, v, acc); }
+
 // Row owned by this lane group for sequential step s; -1 when past the end.
 template <int LPR>
 __device__ __forceinline__ int owned_row(int s, int seq, int n_rows) {
@@ -108,6 +115,7 @@ inline int g_gat_walk = 1;           // K5-K8: 1 = head-major walk over the (nod
 inline int g_cluster_ring = 0;       // form 0: units the gathers run ahead (0 = automatic: 2 if it fits half a CU's LDS, else 1); form 2: ring slots
 inline int g_cluster_per_cu = 0;     // persistent workgroups per CU (0 = automatic)
 inline int g_gat_cluster_waves = 0;  // clustered GAT kernels: waves per workgroup (0 = default)
+inline int g_gat_cluster_depth = 0;  // clustered GAT kernels: units the gathers run ahead of the reduction (0 = default)
 inline int g_gat_cluster_group = 0;  // clustered GAT kernels: clusters walked together through all their slices (0 = the whole span of an XCD)
 inline int g_cluster_consumers = 0;  // form 0: waves per workgroup; form 2: consumer waves (0 = automatic)
 
