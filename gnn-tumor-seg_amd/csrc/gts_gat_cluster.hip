@@ -608,8 +608,10 @@ struct GatPlan {
   int chunk_slots, side_floats, side_pieces, rec_bytes, side_slot_bytes, image_bytes, waves, depth;
   int64_t wg_lds;
 };
-// depth: units the gathers run ahead (GTS_OPT_GAT_CLUSTER_DEPTH; the deepest the LDS holds, at least 1)
-inline GatPlan gat_plan(int max_rows, int max_srcs, int loc_words, bool tagged, bool bwd, bool edge = false) {
+// depth: units the gathers run ahead.  The library runs depth 1 (two images, two workgroups per CU); 2 and 3 are instantiated
+// by tools/diag/gat_whatif.hip only (measured: no gain — the kernels are bound by the vector instructions they issue, and the
+// deeper images leave room for one workgroup per CU; profiles/r04/gat_depth_ab.log)
+inline GatPlan gat_plan(int max_rows, int max_srcs, int loc_words, bool tagged, bool bwd, bool edge = false, int depth = 1) {
   GatPlan p;
   p.chunk_slots = loc_words / 2;
   p.side_floats = p.chunk_slots * 8 + (bwd ? max_rows * 2 : 0);
@@ -618,7 +620,7 @@ inline GatPlan gat_plan(int max_rows, int max_srcs, int loc_words, bool tagged, 
   p.side_slot_bytes = 1024 * p.side_pieces;
   p.image_bytes = (((max_srcs + 1) & ~1) + (edge ? (max_rows + 1) & ~1 : 0)) * kHalfBytes;   // edge pass: the rows' own slices behind the neighbours'
   p.waves = g_gat_cluster_waves > 0 ? std::max(4, std::min(16, g_gat_cluster_waves)) : 12;
-  for (p.depth = std::max(1, std::min(3, g_gat_cluster_depth > 0 ? g_gat_cluster_depth : 1));; --p.depth) {
+  for (p.depth = std::max(1, std::min(3, depth));; --p.depth) {
     const int64_t slots = p.depth + std::max(1, p.depth - 1) + 1;
     p.wg_lds = slots * p.rec_bytes + (edge ? 0 : slots * (p.side_slot_bytes + 1024)) + (p.depth + 1LL) * p.image_bytes;
     if (p.wg_lds <= kMaxLds || p.depth == 1) break;
@@ -641,7 +643,7 @@ inline bool bad_gat_cluster(int64_t n_clusters, int32_t max_rows, int32_t max_sr
   return false;
 }
 
-template <int MODE, int WHATIF = 0>
+template <int MODE, int WHATIF = 0, int MAXDEPTH = 1>
 int launch_gat_cluster(GatClusterArgs a, const GatPlan& p, hipStream_t st) {
   a.side_floats = p.side_floats, a.chunk_slots = p.chunk_slots, a.side_pieces = p.side_pieces;
   a.rec_bytes = p.rec_bytes, a.side_slot_bytes = p.side_slot_bytes, a.image_bytes = p.image_bytes;
@@ -663,14 +665,14 @@ int launch_gat_cluster(GatClusterArgs a, const GatPlan& p, hipStream_t st) {
     kernel<<<dim3(static_cast<unsigned>(grid)), p.waves * kWave, p.wg_lds, st>>>(a);
     return launch_status();
   };
-  if (p.waves > 12) {
-    if (p.depth == 3) return go(gat_cluster_stream_kernel<MODE, 8, 3, WHATIF>);
-    if (p.depth == 2) return go(gat_cluster_stream_kernel<MODE, 8, 2, WHATIF>);
-    return go(gat_cluster_stream_kernel<MODE, 8, 1, WHATIF>);
+  if constexpr (MAXDEPTH >= 3) {
+    if (p.depth == 3) return p.waves > 12 ? go(gat_cluster_stream_kernel<MODE, 8, 3, WHATIF>) : go(gat_cluster_stream_kernel<MODE, 6, 3, WHATIF>);
   }
-  if (p.depth == 3) return go(gat_cluster_stream_kernel<MODE, 6, 3, WHATIF>);
-  if (p.depth == 2) return go(gat_cluster_stream_kernel<MODE, 6, 2, WHATIF>);
-  return go(gat_cluster_stream_kernel<MODE, 6, 1, WHATIF>);
+  if constexpr (MAXDEPTH >= 2) {
+    if (p.depth == 2) return p.waves > 12 ? go(gat_cluster_stream_kernel<MODE, 8, 2, WHATIF>) : go(gat_cluster_stream_kernel<MODE, 6, 2, WHATIF>);
+  }
+  if (p.depth != 1) return GTS_ERR_ARGKIND;
+  return p.waves > 12 ? go(gat_cluster_stream_kernel<MODE, 8, 1, WHATIF>) : go(gat_cluster_stream_kernel<MODE, 6, 1, WHATIF>);
 }
 
 template <typename Launch>

@@ -132,30 +132,58 @@ __device__ __forceinline__ int reduce_winner_rows(const ClusterArgs& a, const in
     const bool have = j < n_rows;
     const uint32_t ri = have ? info[j] : 0u;
     const int c0 = ri & 0xFFFF, deg = ri >> 16;
-    const int deg_w = max(__builtin_amdgcn_readlane(deg, 0), __builtin_amdgcn_readlane(deg, 32));
+    const int deg_a = __builtin_amdgcn_readlane(deg, 0), deg_b = __builtin_amdgcn_readlane(deg, 32);
+    const int deg_w = max(deg_a, deg_b);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; 8 * c < deg_w; ++c) {
-      const int at = 8 * c < deg ? c0 + c : c0;
-      const uint2 w = loc[at], tg = tag[at];
-      for_count(min(8, deg_w - 8 * c), [&](auto cnt_c) {
-        constexpr int CNT = decltype(cnt_c)::value;
-        float4 g[CNT];
-        uint32_t win[CNT];
+    if (deg_a == deg_b && deg_w <= 8) {
+      // the common pair: equal degrees, one chunk — the exact count is both rows' count, no per-edge masks (the kernel issues
+      // vector instructions for about as long as its memory traffic takes: every one saved shows, profiles/r04)
+      if (deg_w > 0) {
+        const uint2 w = loc[c0], tg = tag[c0];
+        for_count(deg_w, [&](auto cnt_c) {
+          constexpr int CNT = decltype(cnt_c)::value;
+          float4 g[CNT];
+          uint32_t win[CNT];
 #pragma unroll
-        for (int q = 0; q < CNT; ++q) {
-          const unsigned s = chunk_byte(w, q);
-          g[q] = *reinterpret_cast<const float4*>(my_g + s * kHalfBytes);
-          win[q] = *reinterpret_cast<const uint32_t*>(my_w + s * kArgHalfBytes);
-        }
+          for (int q = 0; q < CNT; ++q) {
+            const unsigned s = chunk_byte(w, q);
+            g[q] = *reinterpret_cast<const float4*>(my_g + s * kHalfBytes);
+            win[q] = *reinterpret_cast<const uint32_t*>(my_w + s * kArgHalfBytes);
+          }
 #pragma unroll
-        for (int q = 0; q < CNT; ++q) {
-          const unsigned want = chunk_byte(tg, q);
-          const bool live = 8 * c + q < deg;
-          const float g4[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
+          for (int q = 0; q < CNT; ++q) {
+            const unsigned want = chunk_byte(tg, q);
+            acc[0] += (win[q] & 0xFF) == want ? g[q].x : 0.0f;
+            acc[1] += ((win[q] >> 8) & 0xFF) == want ? g[q].y : 0.0f;
+            acc[2] += ((win[q] >> 16) & 0xFF) == want ? g[q].z : 0.0f;
+            acc[3] += (win[q] >> 24) == want ? g[q].w : 0.0f;
+          }
+        });
+      }
+    } else {
+      for (int c = 0; 8 * c < deg_w; ++c) {
+        const int at = 8 * c < deg ? c0 + c : c0;
+        const uint2 w = loc[at], tg = tag[at];
+        for_count(min(8, deg_w - 8 * c), [&](auto cnt_c) {
+          constexpr int CNT = decltype(cnt_c)::value;
+          float4 g[CNT];
+          uint32_t win[CNT];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t] += (live && ((win[q] >> (8 * t)) & 0xFF) == want) ? g4[t] : 0.0f;
-        }
-      });
+          for (int q = 0; q < CNT; ++q) {
+            const unsigned s = chunk_byte(w, q);
+            g[q] = *reinterpret_cast<const float4*>(my_g + s * kHalfBytes);
+            win[q] = *reinterpret_cast<const uint32_t*>(my_w + s * kArgHalfBytes);
+          }
+#pragma unroll
+          for (int q = 0; q < CNT; ++q) {
+            const unsigned want = chunk_byte(tg, q);
+            const bool live = 8 * c + q < deg;
+            const float g4[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] += (live && ((win[q] >> (8 * t)) & 0xFF) == want) ? g4[t] : 0.0f;
+          }
+        });
+      }
     }
     if (have) {
       const size_t off = static_cast<size_t>(l_rec[a.layout.rows + j]) * kF + part * (kF / 2) + hl * 4;

@@ -8,7 +8,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgts_hip.so")
+# GTS_LIB_PATH: another build of the same library (A/B runs of two builds in one session, tools/); the default is the in-tree build
+LIB_PATH = os.environ.get("GTS_LIB_PATH") or os.path.join(_HERE, "libgts_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "gts_hip.h")
 ABI_VERSION = 20
 

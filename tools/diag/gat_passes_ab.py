@@ -1,9 +1,9 @@
 """The three clustered GAT aggregation calls (forward, edge pass, source pass) at C3's hidden-layer shape, 20 times each between HIP
-events, for the knobs of the streaming kernel: clusters walked together (--group), workgroups per CU, waves, gather depth.  Outputs of
+events, for the knobs of the streaming kernel: clusters walked together (--group), workgroups per CU, waves.  Outputs of
 every run are compared bit for bit with the first.  One variant per process suits a rocprofv3 --pmc pass around it.
 (Round 4 also ran this on PITCHED tables — rows 4 KiB + 512 B apart, to spread a slice column over the L2's sets: no change in time or
 in FETCH_SIZE, the L2's set index is hashed; profiles/r04/README.md.)
-Usage: python tools/diag/gat_passes_ab.py [--graphs 4] [--group 0] [--per-cu 1] [--waves 8] [--depth 2]"""
+Usage: python tools/diag/gat_passes_ab.py [--graphs 4] [--group 0] [--per-cu 1] [--waves 8]"""
 import argparse
 import os
 import sys
@@ -36,12 +36,10 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--per-cu", type=int, default=0, help="persistent workgroups per CU (option 11; 0 = default 2)")
     ap.add_argument("--waves", type=int, default=0, help="waves per workgroup (option 15; 0 = default 12)")
-    ap.add_argument("--depth", type=int, default=0, help="units the gathers run ahead (option 17; 0 = default)")
     args = ap.parse_args()
     lib = _lib.load()
     lib.gts_set_option(11, args.per_cu)
     lib.gts_set_option(15, args.waves)
-    lib.gts_set_option(17, args.depth)
     dev = torch.device("cuda:0")
     g = gts.batch([synth.lattice_graph() for _ in range(args.graphs)]).to(dev)
     n, h, d = g.n, 4, 256
@@ -86,7 +84,7 @@ def main():
             if ref is None:
                 ref = got
             same = all(torch.equal(x, y) for x, y in zip(ref, got))
-            print(f"group {group:3d} per_cu {args.per_cu} waves {args.waves} depth {args.depth}: " +
+            print(f"group {group:3d} per_cu {args.per_cu} waves {args.waves}: " +
                   "  ".join(f"{k} {us[k]:7.1f} us = {compulsory[k] / us[k] / 8e6:.3f}" for k in ("fwd", "edge", "src")) +
                   f"  same bits as the first run: {same}", flush=True)
             assert same

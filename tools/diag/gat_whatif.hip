@@ -5,11 +5,13 @@
 // Built and driven by tools/diag/gat_whatif.py.
 #include "../../gnn-tumor-seg_amd/csrc/gts_gat_cluster.hip"
 
+static int g_whatif_depth = 1;   // units the gathers run ahead (the library itself runs 1)
+
 extern "C" int gts_whatif_gat_fwd(const int32_t* rec, int64_t n_clusters, int32_t max_rows, int32_t max_srcs, int32_t loc_words,
                                   const float* ft, const float* bias, int32_t activation, float* out, float* workspace, int64_t n,
                                   int64_t heads, int32_t whatif, void* stream) {
   using namespace gts;
-  const GatPlan p = gat_plan(max_rows, max_srcs, loc_words, false, false);
+  const GatPlan p = gat_plan(max_rows, max_srcs, loc_words, false, false, false, g_whatif_depth);
   GatClusterArgs a{};
   a.rec = rec, a.layout = rec_layout(max_rows, max_srcs, loc_words, false), a.n_clusters = static_cast<int>(n_clusters), a.max_srcs = max_srcs;
   a.table = ft, a.side = workspace, a.vec = bias, a.out = out;
@@ -19,13 +21,13 @@ extern "C" int gts_whatif_gat_fwd(const int32_t* rec, int64_t n_clusters, int32_
   a.vec_bytes = static_cast<unsigned>(heads * kF * 4);
   a.heads = static_cast<int>(heads), a.act = activation, a.nt = 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (whatif == 1) return launch_gat_cluster<0, 1>(a, p, st);
-  if (whatif == 2) return launch_gat_cluster<0, 2>(a, p, st);
-  if (whatif == 3) return launch_gat_cluster<0, 3>(a, p, st);
-  if (whatif == 9) return launch_gat_cluster<0, 9>(a, p, st);   // out = stamp buffer
-  return launch_gat_cluster<0, 0>(a, p, st);
+  if (whatif == 1) return launch_gat_cluster<0, 1, 3>(a, p, st);
+  if (whatif == 2) return launch_gat_cluster<0, 2, 3>(a, p, st);
+  if (whatif == 3) return launch_gat_cluster<0, 3, 3>(a, p, st);
+  if (whatif == 9) return launch_gat_cluster<0, 9, 3>(a, p, st);   // out = stamp buffer
+  return launch_gat_cluster<0, 0, 3>(a, p, st);
 }
 
 extern "C" void gts_whatif_knobs(int32_t depth, int32_t per_cu, int32_t waves, int32_t group) {
-  gts::g_gat_cluster_depth = depth, gts::g_cluster_per_cu = per_cu, gts::g_gat_cluster_waves = waves, gts::g_gat_cluster_group = group;
+  g_whatif_depth = depth, gts::g_cluster_per_cu = per_cu, gts::g_gat_cluster_waves = waves, gts::g_gat_cluster_group = group;
 }

@@ -9,7 +9,7 @@ timeout -k 10 600 python -m pytest tests/test_gpu_gat_cluster.py tests/test_gpu_
 echo "pytest rc=$?"; tail -3 $OUT/pytest.log
 grep -q " passed" $OUT/pytest.log || exit 1
 GTS_DIAG_REBUILD=1 timeout -k 10 300 python tools/diag/gat_whatif.py 4 2>&1 | grep -v 'warning\|amdgpu.ids\|\^\|__global__\|In file' | tee $OUT/whatif.log | grep -v 'per_cu 1'
-for args in "--depth 1" "--depth 1 --waves 8"; do
+for args in "" "--waves 8"; do
   echo "== $args"
   timeout -k 10 200 python tools/diag/gat_passes_ab.py --group 16 $args 2>&1 | grep -v amdgpu.ids | tee -a $OUT/ab.log
 done
