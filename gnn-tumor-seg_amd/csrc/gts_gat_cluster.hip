@@ -76,7 +76,8 @@ __global__ __launch_bounds__(kBlock) void gat_arrange_kernel(const int32_t* __re
                                                              const int32_t* __restrict__ t_pos, const float* __restrict__ attn,
                                                              const float* __restrict__ ge, const float* __restrict__ ger,
                                                              float* __restrict__ gel, float* __restrict__ side, int side_floats,
-                                                             int chunk_slots) {
+                                                             int chunk_slots, unsigned* __restrict__ counters) {
+  if (blockIdx.x == 0) counters[threadIdx.x] = 0u;   // the streaming kernel behind this pass deals its units off them (kBlock = 256 words)
   const long long tid = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x;
   const int per_cluster = max_rows * heads;
   const long long c = tid / per_cluster;
@@ -123,7 +124,9 @@ __global__ __launch_bounds__(kBlock) void gat_weights_one_chunk_kernel(const int
                                                                        float slope, float* __restrict__ attn_out,
                                                                        const float* __restrict__ attn_in, const float* __restrict__ ge,
                                                                        const float* __restrict__ ger, float* __restrict__ gel,
-                                                                       float* __restrict__ side, int side_floats, int chunk_slots) {
+                                                                       float* __restrict__ side, int side_floats, int chunk_slots,
+                                                                       unsigned* __restrict__ counters) {
+  if (blockIdx.x == 0) counters[threadIdx.x] = 0u;   // the streaming kernel behind this pass deals its units off them (kBlock = 256 words)
   // eight lanes per (cluster, row slot); every lane walks the heads (their values sit next to each other in el / er / attn / ge:
   // one dependent chain of index loads per row instead of one per (row, head))
   const unsigned idx = blockIdx.x * static_cast<unsigned>(kBlock) + threadIdx.x;   // < 2^31 (host-checked)
@@ -235,9 +238,11 @@ struct GatClusterArgs {
   unsigned own_bytes;
   int heads, act, nt;
   int side_floats, chunk_slots, side_pieces;
-  int rec_bytes, side_slot_bytes, image_bytes;   // LDS: 3 record slots | 3 side slots | 3 vector slots of 1 KiB | 2 images
+  int rec_bytes, side_slot_bytes, image_bytes;   // LDS: 3 record slots | 3 side slots | 3 vector slots of 1 KiB | 2 images | 64 B of dealt units
+  int deal_off;
   int own_off;             // edge pass: byte offset of the own-row section inside an image
   int group;               // clusters of an XCD's span walked together through all their (head, half) slices (see the kernel)
+  unsigned* counters;      // dynamic dealing: one unit counter per XCD, 32 words apart, zero at launch (null: static round-robin dealing)
 };
 
 // the rows of one unit out of LDS: half a wave per row, 16 B per lane; acc = w_k * slice_k + acc in slot order (`mad`), one
@@ -416,8 +421,17 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
   const int clo = static_cast<int>(static_cast<long long>(a.n_clusters) * xcd / 8);
   const int span = static_cast<int>(static_cast<long long>(a.n_clusters) * (xcd + 1) / 8) - clo;
   const long long n_local = static_cast<long long>(span) * subs;
-  const int n_my = jw < n_local ? static_cast<int>((n_local - jw + per_xcd - 1) / per_xcd) : 0;
-  if (n_my == 0) return;
+  // Dealing.  STATIC (a.counters == nullptr): unit i of the span to workgroup i % per_xcd.  A workgroup that falls ONE unit behind
+  // its neighbours is then per_xcd units behind in the walk — a whole generation — and the halo slices it shares with them have
+  // left the L2 before it asks: with the reduction in the loop the kernel fetched 1.57 x the table where the same walk without it
+  // (all workgroups in step) fetched 1.20 x (profiles/r04/gat_l2_replay.log).  DYNAMIC (the default): the workgroups of an XCD
+  // take their units from ONE counter (an agent-scope atomic add by the workgroup's last wave, one iteration before the unit's
+  // record is fetched; the value goes round through LDS with the iteration's barrier), so the units in flight are always the
+  // latest per_xcd ones of the walk, whatever the pace of each workgroup.  Which workgroup computes a unit changes nothing in what
+  // it computes.
+  const bool dynamic = a.counters != nullptr;
+  const int n_static = jw < n_local ? static_cast<int>((n_local - jw + per_xcd - 1) / per_xcd) : 0;
+  if (!dynamic && n_static == 0) return;
   const int words = a.layout.words;
   const int rec_pieces = a.rec_bytes / 1024;
   unsigned char* side_slots = lds + R * a.rec_bytes;
@@ -456,16 +470,42 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
       }
     }
   };
-  // (cluster, sub) of the units in the pipeline: [0] = the one fetch_record took last ... [PIPE - 1] = the one being reduced
+  // (cluster, sub) of the units in the pipeline: [0] = the one fetch_record took last ... [PIPE - 1] = the one being reduced;
+  // cluster < 0: no unit (the span is exhausted)
   constexpr int PIPE = DEPTH + AHEAD + 1;
   int u_cluster[PIPE], u_sub[PIPE];
 #pragma unroll
-  for (int q = 0; q < PIPE; ++q) u_cluster[q] = clo, u_sub[q] = 0;
-  auto next_unit = [&]() {                   // shift the pipeline, enter the walk's unit at [0], advance the walk
+  for (int q = 0; q < PIPE; ++q) u_cluster[q] = -1, u_sub[q] = 0;
+  int32_t* l_deal = reinterpret_cast<int32_t*>(lds + a.deal_off);   // dynamic dealing: 8 x (cluster, sub); 0 .. PIPE - 2 the prologue's, 6 / 7 the loop's
+  int entered = 0;
+  auto next_unit = [&](int deal_slot) {      // shift the pipeline and enter the next unit at [0]
 #pragma unroll
     for (int q = PIPE - 1; q > 0; --q) u_cluster[q] = u_cluster[q - 1], u_sub[q] = u_sub[q - 1];
-    u_cluster[0] = clo + static_cast<int>(w_first + w_c), u_sub[0] = static_cast<int>(w_s);
-    advance();
+    if (dynamic) {
+      u_cluster[0] = __builtin_amdgcn_readfirstlane(l_deal[2 * deal_slot]);
+      u_sub[0] = __builtin_amdgcn_readfirstlane(l_deal[2 * deal_slot + 1]);
+    } else if (entered < n_static) {
+      u_cluster[0] = clo + static_cast<int>(w_first + w_c), u_sub[0] = static_cast<int>(w_s);
+      advance();
+      ++entered;
+    } else {
+      u_cluster[0] = -1;
+    }
+  };
+  // the dealer (the workgroup's last wave, which fetches no record piece): `count` units off the XCD's counter into l_deal[slot0 ..]
+  auto deal = [&](int count, int slot0) {
+    unsigned base = 0;
+    if (lane == 0) base = __hip_atomic_fetch_add(a.counters + 32 * xcd, static_cast<unsigned>(count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (int q = 0; q < count; ++q) {
+      const unsigned idx = base + q;
+      const bool ok = idx < static_cast<unsigned long long>(n_local);
+      const unsigned sl = idx / static_cast<unsigned>(span);        // the whole span slice by slice
+      if (lane == 0) {
+        l_deal[2 * (slot0 + q)] = ok ? clo + static_cast<int>(idx - sl * static_cast<unsigned>(span)) : -1;
+        l_deal[2 * (slot0 + q) + 1] = ok ? static_cast<int>(sl) : 0;
+      }
+    }
   };
   // record, weights and epilogue vectors of unit t -> their slots, one LDS-DMA per piece and wave.  Returns this wave's count
   auto fetch_record = [&](int t, int cluster_id, int sub) {
@@ -529,15 +569,22 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
   int g_hist[HIST], s_hist[HIST], r_hist[HIST];   // [0] = youngest; wave-uniform counts of this wave's operations
 #pragma unroll
   for (int q = 0; q < HIST; ++q) g_hist[q] = s_hist[q] = r_hist[q] = 0;
+  if (dynamic) {                               // the first PIPE units of this workgroup in one add: PIPE - 1 for the prologue, one for iteration 0
+    if (wave == n_waves - 1) {
+      deal(PIPE - 1, 0);
+      deal(1, 6);
+    }
+    barrier_all();
+  }
 #pragma unroll
   for (int t = 0; t < DEPTH + AHEAD; ++t) {   // afterwards u_*[DEPTH + AHEAD - 1 - t] is unit t
-    next_unit();
-    if (t < n_my) fetch_record(t, u_cluster[0], u_sub[0]);
+    next_unit(t);
+    if (u_cluster[0] >= 0) fetch_record(t, u_cluster[0], u_sub[0]);
   }
   barrier_all();
 #pragma unroll
   for (int t = 0; t < DEPTH; ++t) {
-    const int cnt = t < n_my ? issue_gathers(t, u_sub[DEPTH + AHEAD - 1 - t]) : 0;
+    const int cnt = u_cluster[DEPTH + AHEAD - 1 - t] >= 0 ? issue_gathers(t, u_sub[DEPTH + AHEAD - 1 - t]) : 0;
     if (t >= 1) {                              // the gathers of units 1 .. DEPTH - 1 stay in flight past the first wait
 #pragma unroll
       for (int q = HIST - 1; q > 0; --q) g_hist[q] = g_hist[q - 1];
@@ -555,7 +602,8 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
     }
   };
   if constexpr (WHATIF == 9) stamp = __builtin_amdgcn_s_memtime();
-  for (int it = 0; it < n_my; ++it) {
+  int it = 0;
+  for (;; ++it) {
     int keep = 0;
     if constexpr (DEPTH == 1) {
       keep = s_hist[0];
@@ -569,9 +617,11 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
     lap(0);
     barrier_lds();                          // ... and everyone else's; the oldest image and the oldest slots are free
     lap(1);
-    next_unit();                            // u_*[0] = unit it + DEPTH + AHEAD, [AHEAD] = unit it + DEPTH, [PIPE - 1] = unit it
-    const int recs = it + DEPTH + AHEAD < n_my ? fetch_record(it + DEPTH + AHEAD, u_cluster[0], u_sub[0]) : 0;
-    const int gathers = it + DEPTH < n_my ? issue_gathers(it + DEPTH, u_sub[AHEAD]) : 0;
+    next_unit(6 + (it & 1));                // u_*[0] = unit it + DEPTH + AHEAD, [AHEAD] = unit it + DEPTH, [PIPE - 1] = unit it
+    if (u_cluster[PIPE - 1] < 0) break;     // units come in walk order: nothing behind an empty slot
+    if (dynamic && wave == n_waves - 1) deal(1, 6 + ((it + 1) & 1));   // read after the NEXT barrier; its slot was last read before this one
+    const int recs = u_cluster[0] >= 0 ? fetch_record(it + DEPTH + AHEAD, u_cluster[0], u_sub[0]) : 0;
+    const int gathers = u_cluster[AHEAD] >= 0 ? issue_gathers(it + DEPTH, u_sub[AHEAD]) : 0;
     lap(2);
     const int sub = u_sub[PIPE - 1], cluster = u_cluster[PIPE - 1];
     const int slot = it % R;
@@ -599,7 +649,7 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
     if (threadIdx.x == 0) {
       unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.out) + 8 * static_cast<size_t>(blockIdx.x);
       for (int q = 0; q < 4; ++q) dbg[q] = phase[q];
-      dbg[4] = static_cast<unsigned long long>(n_my);
+      dbg[4] = static_cast<unsigned long long>(it);
     }
   }
 }
@@ -622,7 +672,7 @@ inline GatPlan gat_plan(int max_rows, int max_srcs, int loc_words, bool tagged, 
   p.waves = g_gat_cluster_waves > 0 ? std::max(4, std::min(16, g_gat_cluster_waves)) : 12;
   for (p.depth = std::max(1, std::min(3, depth));; --p.depth) {
     const int64_t slots = p.depth + std::max(1, p.depth - 1) + 1;
-    p.wg_lds = slots * p.rec_bytes + (edge ? 0 : slots * (p.side_slot_bytes + 1024)) + (p.depth + 1LL) * p.image_bytes;
+    p.wg_lds = slots * p.rec_bytes + (edge ? 0 : slots * (p.side_slot_bytes + 1024)) + (p.depth + 1LL) * p.image_bytes + 64;
     if (p.wg_lds <= kMaxLds || p.depth == 1) break;
   }
   return p;
@@ -644,16 +694,19 @@ inline bool bad_gat_cluster(int64_t n_clusters, int32_t max_rows, int32_t max_sr
 }
 
 template <int MODE, int WHATIF = 0, int MAXDEPTH = 1>
-int launch_gat_cluster(GatClusterArgs a, const GatPlan& p, hipStream_t st) {
+int launch_gat_cluster(GatClusterArgs a, const GatPlan& p, hipStream_t st, int64_t grid_override = 0) {   // override: tools/diag only
   a.side_floats = p.side_floats, a.chunk_slots = p.chunk_slots, a.side_pieces = p.side_pieces;
   a.rec_bytes = p.rec_bytes, a.side_slot_bytes = p.side_slot_bytes, a.image_bytes = p.image_bytes;
   a.own_off = ((a.max_srcs + 1) & ~1) * kHalfBytes;
+  a.deal_off = static_cast<int>(p.wg_lds) - 64;
+  if (g_gat_cluster_dealing == 1) a.counters = nullptr;   // static round-robin dealing (A/B runs)
   a.group = g_gat_cluster_group > 0 ? g_gat_cluster_group : 16;   // profiles/r04: source pass 152 -> 146 us, the other two passes unchanged
   const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({g_cluster_per_cu > 0 ? g_cluster_per_cu : 2, kMaxLds / p.wg_lds,
                                                                                static_cast<int64_t>(32 / p.waves)})));
   const int64_t units = 2LL * a.heads * a.n_clusters;
   int64_t grid = static_cast<int64_t>(device_cus()) * per_cu;
   grid = std::max<int64_t>(8, std::min(grid, (units + 7) / 8 * 8)) / 8 * 8;
+  if (grid_override > 0) grid = (grid_override + 7) / 8 * 8;
   auto go = [&](auto kernel) {
     static std::mutex guard;               // the LDS attribute once per kernel, not per launch
     static std::vector<const void*> allowed;
@@ -675,6 +728,11 @@ int launch_gat_cluster(GatClusterArgs a, const GatPlan& p, hipStream_t st) {
   return p.waves > 12 ? go(gat_cluster_stream_kernel<MODE, 8, 1, WHATIF>) : go(gat_cluster_stream_kernel<MODE, 6, 1, WHATIF>);
 }
 
+constexpr int64_t kCounterBytes = 1024;   // 8 XCDs x 32 words: every counter on a line of its own
+inline int64_t weight_block_bytes(int64_t n_clusters, int64_t heads, int64_t side_floats) {
+  return (n_clusters * heads * side_floats * static_cast<int64_t>(sizeof(float)) + 255) / 256 * 256;
+}
+
 template <typename Launch>
 int for_group_size(int64_t max_degree, Launch&& launch) {
   if (max_degree <= 8) return launch(IC<8>{});
@@ -690,7 +748,7 @@ extern "C" int64_t gts_gat_cluster_workspace(int64_t n_clusters, int32_t max_row
                                              int32_t backward) {
   if (n_clusters < 0 || max_rows < 1 || loc_words < 2 || heads < 1) return 0;
   const int64_t side_floats = (loc_words / 2) * 8 + (backward ? max_rows * 2 : 0);
-  return n_clusters * heads * side_floats * static_cast<int64_t>(sizeof(float));
+  return gts::weight_block_bytes(n_clusters, heads, side_floats) + gts::kCounterBytes;   // the unit counters of the streaming kernel behind the blocks
 }
 
 extern "C" int32_t gts_gat_attn_f32(const int32_t* indptr, const int32_t* indices, const float* el, const float* er,
@@ -728,24 +786,25 @@ extern "C" int32_t gts_gat_fwd_cluster_f32(const int32_t* indptr, const int32_t*
   const RecLayout lay = rec_layout(max_rows, max_srcs, loc_words, tagged != 0);
   const int nh = static_cast<int>(heads);
   const int64_t threads = n_clusters * max_rows * heads;
+  unsigned* counters = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(workspace) + weight_block_bytes(n_clusters, heads, p.side_floats));
   int rc = GTS_OK;
   if (max_degree <= 8) {
     if (!indices && max_degree > 0) return GTS_ERR_NULL;
     gat_weights_one_chunk_kernel<false><<<static_cast<unsigned>((8 * (threads / heads) + kBlock - 1) / kBlock), kBlock, 0, st>>>(
         rec, lay, static_cast<int>(n_clusters), max_rows, nh, indptr, indices, el, er, negative_slope, attn, nullptr, nullptr, nullptr,
-        nullptr, workspace, p.side_floats, p.chunk_slots);
+        nullptr, workspace, p.side_floats, p.chunk_slots, counters);
   } else {
     rc = gts_gat_attn_f32(indptr, indices, el, er, negative_slope, attn, n, heads, max_degree, stream);
     if (rc != GTS_OK) return rc;
     gat_arrange_kernel<false><<<static_cast<unsigned>((threads + kBlock - 1) / kBlock), kBlock, 0, st>>>(
         rec, lay, static_cast<int>(n_clusters), max_rows, nh, indptr, nullptr, attn, nullptr, nullptr, nullptr, workspace, p.side_floats,
-        p.chunk_slots);
+        p.chunk_slots, counters);
   }
   rc = launch_status();
   if (rc != GTS_OK) return rc;
   GatClusterArgs a{};
   a.rec = rec, a.layout = lay, a.n_clusters = static_cast<int>(n_clusters), a.max_srcs = max_srcs;
-  a.table = ft, a.side = workspace, a.vec = bias, a.out = out;
+  a.table = ft, a.side = workspace, a.vec = bias, a.out = out, a.counters = counters;
   a.row_bytes = static_cast<unsigned>(heads * kF * 4);
   a.table_bytes = static_cast<unsigned>(n * a.row_bytes);
   a.side_bytes = static_cast<unsigned>(n_clusters * heads * p.side_floats * 4);
@@ -770,18 +829,20 @@ extern "C" int32_t gts_gat_bwd_src_cluster_f32(const int32_t* t_indptr, const in
   const RecLayout lay = rec_layout(max_rows, max_srcs, loc_words, tagged != 0);
   const int nh = static_cast<int>(heads);
   const int64_t threads = n_clusters * max_rows * heads;
+  unsigned* counters = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(workspace) + weight_block_bytes(n_clusters, heads, p.side_floats));
   if (max_degree >= 0 && max_degree <= 8)
     gat_weights_one_chunk_kernel<true><<<static_cast<unsigned>((8 * (threads / heads) + kBlock - 1) / kBlock), kBlock, 0, st>>>(
         rec, lay, static_cast<int>(n_clusters), max_rows, nh, t_indptr, t_pos, nullptr, nullptr, 0.0f, nullptr, attn, ge, ger, gel,
-        workspace, p.side_floats, p.chunk_slots);
+        workspace, p.side_floats, p.chunk_slots, counters);
   else
     gat_arrange_kernel<true><<<static_cast<unsigned>((threads + kBlock - 1) / kBlock), kBlock, 0, st>>>(
-        rec, lay, static_cast<int>(n_clusters), max_rows, nh, t_indptr, t_pos, attn, ge, ger, gel, workspace, p.side_floats, p.chunk_slots);
+        rec, lay, static_cast<int>(n_clusters), max_rows, nh, t_indptr, t_pos, attn, ge, ger, gel, workspace, p.side_floats, p.chunk_slots,
+        counters);
   const int rc = launch_status();
   if (rc != GTS_OK) return rc;
   GatClusterArgs a{};
   a.rec = rec, a.layout = lay, a.n_clusters = static_cast<int>(n_clusters), a.max_srcs = max_srcs;
-  a.table = gout, a.side = workspace, a.vec = attn_lr, a.out = gft;
+  a.table = gout, a.side = workspace, a.vec = attn_lr, a.out = gft, a.counters = counters;
   a.row_bytes = static_cast<unsigned>(heads * kF * 4);
   a.table_bytes = static_cast<unsigned>(n * a.row_bytes);
   a.side_bytes = static_cast<unsigned>(n_clusters * heads * p.side_floats * 4);
@@ -807,7 +868,10 @@ extern "C" int32_t gts_gat_bwd_edge_cluster_f32(const int32_t* indptr, const int
   const RecLayout lay = rec_layout(max_rows, max_srcs, loc_words, tagged != 0);
   GatClusterArgs a{};
   a.rec = rec, a.layout = lay, a.n_clusters = static_cast<int>(n_clusters), a.max_srcs = max_srcs;
-  a.table = ft, a.own = gout, a.out = workspace;
+  // the two halves' partial dot products, then the unit counters (no pass of ours runs in front: a memset node zeroes them)
+  unsigned* counters = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(workspace) + 2 * weight_block_bytes(n_clusters, heads, p.side_floats));
+  if (g_gat_cluster_dealing != 1 && hipMemsetAsync(counters, 0, kCounterBytes, st) != hipSuccess) return launch_status();
+  a.table = ft, a.own = gout, a.out = workspace, a.counters = counters;
   a.row_bytes = a.own_row_bytes = static_cast<unsigned>(heads * kF * 4);
   a.table_bytes = static_cast<unsigned>(n * a.row_bytes), a.own_bytes = static_cast<unsigned>(n * a.own_row_bytes);
   a.heads = static_cast<int>(heads);

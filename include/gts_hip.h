@@ -456,6 +456,8 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
 #define GTS_OPT_GAT_CLUSTER_WAVES 15 /* clustered GAT aggregation: waves per persistent workgroup (0 = default 12; up to 16) */
 #define GTS_OPT_GAT_CLUSTER_GROUP 16 /* clustered GAT aggregation: clusters of an XCD's span walked together through all their (head, half) slices
                                         (0 = automatic: 16) */
+#define GTS_OPT_GAT_CLUSTER_DEALING 17 /* clustered GAT aggregation: 0 = the workgroups of an XCD take their units off one counter (default: the units in
+                                         flight stay neighbours in the walk whatever each workgroup's pace), 1 = static round-robin (A/B runs) */
 #define GTS_OPT_PANEL_ROWS 13        /* K11 direct-to-fragment panels: rows per panel, 0 = automatic among 240 / 192 / 144 */
 #define GTS_OPT_CLUSTER_RING 10      /* clustered K1 / K2: units the gathers run ahead of the reduction (0 = automatic: 1; 2 where the LDS holds it) */
 #define GTS_OPT_CLUSTER_PER_CU 11    /* clustered K1 / K2: persistent workgroups per CU (0 = automatic: 2, or 3 for short backward launches) */

@@ -97,6 +97,35 @@ def test_clustered_gat_forward_and_source_pass_equal_the_plain_kernels_bit_for_b
             assert torch.equal(a, w), what
 
 
+@pytest.mark.parametrize("name", ["lattice_large", "batch", "generator_b"])
+def test_units_dealt_off_the_counters_and_round_robin_give_the_same_bits(name):
+    """The streaming kernel's workgroups take their units off one counter per XCD (GTS_OPT_GAT_CLUSTER_DEALING 0, the default) or
+    round-robin (1): which workgroup computes a row changes nothing in the row — repeated launches included (the counters are
+    zeroed by every call)."""
+    lib = _lib.load()
+    g = _graphs()[name]
+    gd = g.to(DEV)
+    heads = 4
+    ft, el, er = _inputs(g, heads, 3)
+    b = torch.randn(heads * 256, generator=torch.Generator().manual_seed(5)).to(DEV)
+    gout = torch.randn(g.n, heads, 256, generator=torch.Generator().manual_seed(6)).to(DEV)
+    al = torch.randn(heads, 256, generator=torch.Generator().manual_seed(7)).to(DEV)
+    ar = torch.randn(heads, 256, generator=torch.Generator().manual_seed(8)).to(DEV)
+    assert lib.gts_get_option(17) == 0
+    results = []
+    try:
+        for dealing in (0, 1, 0, 0):
+            assert lib.gts_set_option(17, dealing) == 0
+            out, attn = ops._gat_fwd(gd, ft, el, er, 0.2, bias=b, activation=1)
+            results.append((out, attn) + tuple(ops._gat_bwd(gd, ft, el, er, attn, gout, 0.2, al, ar)))
+    finally:
+        lib.gts_set_option(17, 0)
+    assert lib.gts_set_option(17, 2) != 0
+    for other in results[1:]:
+        for a, w in zip(other, results[0]):
+            assert torch.equal(a, w)
+
+
 @pytest.mark.parametrize("name", ["lattice", "lattice_self_loops", "batch"])
 def test_clustered_gatconv_layer_with_bias_and_elu_matches_the_oracle(name):
     """One GATConv layer (bias + ELU, 4 heads x 256: the C3 hidden layer of /root/reference/model/networks.py:52) on a
