@@ -74,7 +74,7 @@ __device__ __forceinline__ void gat_row_epilogue(const float (&acc)[VEC], float*
   }
   if (act == 1) {
 #pragma unroll
-    for (int t = 0; t < VEC; ++t) o.v[t] = o.v[t] > 0.0f ? o.v[t] : expm1f(o.v[t]);
+    for (int t = 0; t < VEC; ++t) o.v[t] = o.v[t] > 0.0f ? o.v[t] : elu_expm1(o.v[t]);
   }
   if (active) o.store(out + static_cast<size_t>(r) * dim + c);
 }

@@ -320,12 +320,12 @@ __device__ __forceinline__ int reduce_wsum_rows(const GatClusterArgs& a, const i
         const float4 bs = *reinterpret_cast<const float4*>(l_vec + hl * 4);
         o.v[0] += bs.x, o.v[1] += bs.y, o.v[2] += bs.z, o.v[3] += bs.w;
       }
-      if (a.act == 1) {   // straight-line: four independent expm1f chains, then the selects (same values as the branchy form, NaN included)
-        float e[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) e[t] = expm1f(o.v[t]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) o.v[t] = o.v[t] > 0.0f ? o.v[t] : e[t];
+      if (a.act == 1) {   // ELU: both pairs through elu_expm1_pair (gts_rows.h), then the selects — NaN included
+        const v2f lo = elu_expm1_pair(v2f{o.v[0], o.v[1]}), hi = elu_expm1_pair(v2f{o.v[2], o.v[3]});
+        o.v[0] = o.v[0] > 0.0f ? o.v[0] : lo.x;
+        o.v[1] = o.v[1] > 0.0f ? o.v[1] : lo.y;
+        o.v[2] = o.v[2] > 0.0f ? o.v[2] : hi.x;
+        o.v[3] = o.v[3] > 0.0f ? o.v[3] : hi.y;
       }
     }
     if constexpr (NOSTORE) {

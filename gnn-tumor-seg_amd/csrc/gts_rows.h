@@ -16,6 +16,39 @@ constexpr int kUnroll = 8;
 // the oracle comparison holds at the stated tolerance either way (one rounding instead of two per term).
 __device__ __forceinline__ float mad(float w, float v, float acc) { return __builtin_fmaf(w, v, acc); }
 
+// exp(x) - 1 for the negative branch of ELU (GATConv's activation, model/networks.py:52 -> F.elu; torch computes expm1), x <= 0:
+//   x >= -0.35: x + x^2 (1/2 + x/6 + ... + x^5 / 5040) — the series, cut where its next term is a quarter of an ulp of x;
+//   x <  -0.35: 2^(x log2 e) - 1 on v_exp_f32 (the result is <= -0.29, the subtraction costs at most a bit);
+// about 2 ulp from expm1 at worst (tests/test_gpu_kernels.py compares with torch's at every magnitude), -inf -> -1, NaN -> NaN.
+// The clustered forward kernel issues vector instructions for longer than its memory traffic takes (profiles/r04), and ocml's
+// expm1f was half of them: this form is a third as long and pairs up on v_pk_fma_f32 (`elu_expm1_pair`: the same operations on two
+// elements, so the plain kernels' scalar form and the clustered kernels' paired form give the same bits).
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr float kEluSplit = -0.35f, kLog2e = 1.44269504088896340736f;
+constexpr float kEluC2 = 0.5f, kEluC3 = 1.0f / 6.0f, kEluC4 = 1.0f / 24.0f, kEluC5 = 1.0f / 120.0f, kEluC6 = 1.0f / 720.0f,
+                kEluC7 = 1.0f / 5040.0f;
+__device__ __forceinline__ float elu_expm1(float x) {
+  float q = __builtin_fmaf(kEluC7, x, kEluC6);
+  q = __builtin_fmaf(q, x, kEluC5);
+  q = __builtin_fmaf(q, x, kEluC4);
+  q = __builtin_fmaf(q, x, kEluC3);
+  q = __builtin_fmaf(q, x, kEluC2);
+  const float small = __builtin_fmaf(x * x, q, x);
+  const float large = __builtin_amdgcn_exp2f(x * kLog2e) - 1.0f;
+  return x < kEluSplit ? large : small;
+}
+__device__ __forceinline__ v2f elu_expm1_pair(v2f x) {
+  v2f q = __builtin_elementwise_fma(v2f{kEluC7, kEluC7}, x, v2f{kEluC6, kEluC6});
+  q = __builtin_elementwise_fma(q, x, v2f{kEluC5, kEluC5});
+  q = __builtin_elementwise_fma(q, x, v2f{kEluC4, kEluC4});
+  q = __builtin_elementwise_fma(q, x, v2f{kEluC3, kEluC3});
+  q = __builtin_elementwise_fma(q, x, v2f{kEluC2, kEluC2});
+  const v2f small = __builtin_elementwise_fma(x * x, q, x);
+  const v2f arg = x * v2f{kLog2e, kLog2e};
+  const v2f large = v2f{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)} - v2f{1.0f, 1.0f};
+  return v2f{x.x < kEluSplit ? large.x : small.x, x.y < kEluSplit ? large.y : small.y};
+}
+
 // Row owned by this lane group for sequential step s; -1 when past the end.
 template <int LPR>
 __device__ __forceinline__ int owned_row(int s, int seq, int n_rows) {

@@ -201,6 +201,33 @@ def test_gat_aggregate_hubs_and_isolated_sources(heads, dim):
         assert torch.allclose(got.grad.cpu(), want.grad, rtol=1e-4, atol=5e-5), name
 
 
+@pytest.mark.parametrize("dim", [256, 64, 3])
+def test_gat_elu_is_torchs_expm1_to_a_few_ulp_at_every_magnitude(dim):
+    """GATConv's activation (model/networks.py:52: F.elu, which torch computes with expm1).  The kernels' own form (csrc/gts_rows.h
+    elu_expm1: a series near zero, v_exp_f32 below -0.35) on a graph of self-loops only — one in-edge of weight exactly 1, so
+    out = elu(ft) — against torch at magnitudes 1e-30 .. 100 and around the split: relative error below 4 ulp (5e-7)."""
+    n, heads = 4096, 2
+    idx = np.arange(n)
+    g = gts.Graph(idx.astype("int32"), idx.astype("int32"), n)
+    mags = torch.logspace(-30, 2, n * heads * dim, dtype=torch.float64)
+    ft = -mags.to(torch.float32).reshape(n, heads, dim)
+    ft[:, :, 0] = torch.linspace(-0.36, -0.34, n).reshape(n, 1)                  # around the split
+    ft[0, 0, :3] = torch.tensor([float("-inf"), 0.0, 5.0])
+    el = torch.zeros(n, heads)
+    out, attn = ops._gat_fwd(g.to(DEV), ft.to(DEV), el.to(DEV), el.to(DEV), 0.2, activation=1)
+    assert torch.equal(attn.cpu(), torch.ones(n, heads))
+    want = torch.nn.functional.elu(ft.double())
+    got = out.cpu().double()
+    assert got[0, 0, 0].item() == -1.0 and got[0, 0, 1].item() == 0.0 and got[0, 0, 2].item() == 5.0
+    finite = torch.isfinite(want)
+    rel = ((got - want).abs() / want.abs().clamp_min(1e-300))[finite & (want != 0)]
+    assert rel.max().item() < 5e-7, rel.max().item()
+    nan_in = ft.clone()
+    nan_in[1, 1, 1] = float("nan")
+    out2, _ = ops._gat_fwd(g.to(DEV), nan_in.to(DEV), el.to(DEV), el.to(DEV), 0.2, activation=1)
+    assert torch.isnan(out2[1, 1, 1]).item() and torch.isnan(out2).sum().item() == 1
+
+
 # ------------------------------------------------------------------ K12
 def test_projection_matches_reference_fixture(golden_dir):
     fx = np.load(os.path.join(golden_dir, "ref_project.npz"))
