@@ -492,11 +492,16 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
       u_cluster[0] = -1;
     }
   };
-  // the dealer (the workgroup's last wave, which fetches no record piece): `count` units off the XCD's counter into l_deal[slot0 ..]
-  auto deal = [&](int count, int slot0) {
+  // the dealer (the workgroup's last wave, which fetches no record piece): `count` units off the XCD's counter (take) into
+  // l_deal[slot0 ..] (publish).  In the loop the add is issued in one iteration and published at the top of the next, behind the
+  // wait every wave makes there anyway: the dealer never waits for the counter's round trip on its own.
+  auto take = [&](int count) {
     unsigned base = 0;
     if (lane == 0) base = __hip_atomic_fetch_add(a.counters + 32 * xcd, static_cast<unsigned>(count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    base = __builtin_amdgcn_readfirstlane(base);
+    return base;
+  };
+  auto publish = [&](unsigned taken, int count, int slot0) {
+    const unsigned base = __builtin_amdgcn_readfirstlane(taken);
     for (int q = 0; q < count; ++q) {
       const unsigned idx = base + q;
       const bool ok = idx < static_cast<unsigned long long>(n_local);
@@ -571,11 +576,12 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
   for (int q = 0; q < HIST; ++q) g_hist[q] = s_hist[q] = r_hist[q] = 0;
   if (dynamic) {                               // the first PIPE units of this workgroup in one add: PIPE - 1 for the prologue, one for iteration 0
     if (wave == n_waves - 1) {
-      deal(PIPE - 1, 0);
-      deal(1, 6);
+      publish(take(PIPE - 1), PIPE - 1, 0);
+      publish(take(1), 1, 6);
     }
     barrier_all();
   }
+  unsigned taken = 0;                          // the dealer's add of the iteration before
 #pragma unroll
   for (int t = 0; t < DEPTH + AHEAD; ++t) {   // afterwards u_*[DEPTH + AHEAD - 1 - t] is unit t
     next_unit(t);
@@ -614,12 +620,13 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
       for (int q = 0; q < DEPTH - 2; ++q) keep += r_hist[q];
     }
     wait_vm_all_but(keep);
+    if (dynamic && it > 0 && wave == n_waves - 1) publish(taken, 1, 6 + (it & 1));   // this slot was last read two barriers ago
     lap(0);
     barrier_lds();                          // ... and everyone else's; the oldest image and the oldest slots are free
     lap(1);
     next_unit(6 + (it & 1));                // u_*[0] = unit it + DEPTH + AHEAD, [AHEAD] = unit it + DEPTH, [PIPE - 1] = unit it
     if (u_cluster[PIPE - 1] < 0) break;     // units come in walk order: nothing behind an empty slot
-    if (dynamic && wave == n_waves - 1) deal(1, 6 + ((it + 1) & 1));   // read after the NEXT barrier; its slot was last read before this one
+    if (dynamic && wave == n_waves - 1) taken = take(1);   // published at the top of the next iteration
     const int recs = u_cluster[0] >= 0 ? fetch_record(it + DEPTH + AHEAD, u_cluster[0], u_sub[0]) : 0;
     const int gathers = u_cluster[AHEAD] >= 0 ? issue_gathers(it + DEPTH, u_sub[AHEAD]) : 0;
     lap(2);

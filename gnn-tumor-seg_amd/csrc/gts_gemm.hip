@@ -1527,6 +1527,10 @@ extern "C" int32_t gts_set_option(int32_t option, int32_t value) {
     case GTS_OPT_GAT_WALK: gts::g_gat_walk = value; return GTS_OK;
     case GTS_OPT_GAT_CLUSTER_WAVES: gts::g_gat_cluster_waves = value; return GTS_OK;
     case GTS_OPT_GAT_CLUSTER_GROUP: gts::g_gat_cluster_group = value; return GTS_OK;
+    case GTS_OPT_CLUSTER_DEALING:
+      if (value != 0 && value != 1) return GTS_ERR_ARGKIND;
+      gts::g_cluster_dealing = value;
+      return GTS_OK;
     case GTS_OPT_GAT_CLUSTER_DEALING:
       if (value != 0 && value != 1) return GTS_ERR_ARGKIND;
       gts::g_gat_cluster_dealing = value;
@@ -1553,6 +1557,7 @@ extern "C" int32_t gts_get_option(int32_t option) {
     case GTS_OPT_GAT_CLUSTER_WAVES: return gts::g_gat_cluster_waves;
     case GTS_OPT_GAT_CLUSTER_GROUP: return gts::g_gat_cluster_group;
     case GTS_OPT_GAT_CLUSTER_DEALING: return gts::g_gat_cluster_dealing;
+    case GTS_OPT_CLUSTER_DEALING: return gts::g_cluster_dealing;
     case GTS_OPT_CLUSTER_RING: return gts::g_cluster_ring;
     case GTS_OPT_CLUSTER_PER_CU: return gts::g_cluster_per_cu;
     case GTS_OPT_CLUSTER_CONSUMERS: return gts::g_cluster_consumers;

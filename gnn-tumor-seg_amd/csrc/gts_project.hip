@@ -191,7 +191,7 @@ inline void launch_project_argmax(const int16_t* svs, const float* logits, const
 }  // namespace
 }  // namespace gts
 
-extern "C" int32_t gts_abi_version(void) { return 20; }
+extern "C" int32_t gts_abi_version(void) { return 21; }
 
 extern "C" const char* gts_error_string(int32_t code) {
   switch (code) {

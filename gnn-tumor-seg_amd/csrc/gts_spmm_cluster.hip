@@ -47,6 +47,9 @@ struct ClusterArgs {
   unsigned table_bytes, winners_bytes;
   int relu_input, nt;
   int ring, slot_bytes, image_off, win_off;   // LDS: ring slots of slot_bytes = [record | image | winner image]
+  int deal_off;            // LDS: 64 bytes of dealt units behind the images
+  unsigned* counters;      // dynamic dealing: per XCD a unit counter (word 32 x) and a count of finished workgroups (word 32 x + 16),
+                           // zero on entry and on exit (null: static round-robin dealing)
 };
 
 // ---- reduce the rows of one unit out of its LDS slot ------------------------------------------------------
@@ -223,8 +226,15 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
   const long long n_units = 2LL * a.n_clusters;
   const int lo = static_cast<int>(n_units * xcd / 8), hi = static_cast<int>(n_units * (xcd + 1) / 8);
-  const int n_my = lo + j < hi ? (hi - lo - j + per_xcd - 1) / per_xcd : 0;   // units lo + j + t * per_xcd, t < n_my
-  if (n_my == 0) return;
+  // Dealing (as in gat_cluster_stream_kernel, see there).  STATIC (a.counters == nullptr): unit lo + j + t * per_xcd is this workgroup's
+  // t-th.  DYNAMIC (the default): the XCD's workgroups take their units off one counter, in the order "every cluster of the XCD's span for
+  // the left half, then for the right half" — the units in flight stay neighbours in that walk whatever each workgroup's pace, and their
+  // halo rows meet in the XCD's L2 (a workgroup one unit behind under static dealing is per_xcd units behind in the walk).
+  const bool dynamic = a.counters != nullptr;
+  const int n_static = lo + j < hi ? (hi - lo - j + per_xcd - 1) / per_xcd : 0;   // units lo + j + t * per_xcd, t < n_static
+  if (!dynamic && n_static == 0) return;
+  const int clo = static_cast<int>(static_cast<long long>(a.n_clusters) * xcd / 8);
+  const int span = static_cast<int>(static_cast<long long>(a.n_clusters) * (xcd + 1) / 8) - clo;
   const int words = a.layout.words;
   const int pieces = (words + 255) / 256;   // a record arrives as one or two whole 1 KiB LDS-DMA pieces (lanes past its end deliver zeros)
   const int rec_bytes = 1024 * pieces, image_bytes = a.slot_bytes - a.image_off;
@@ -236,19 +246,55 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
   const RawDma rr(a.rec, static_cast<unsigned>(a.n_clusters) * words * 4u);
   const RawDma rt(a.table, a.table_bytes);
   const RawDma rw(a.winners, BWD ? a.winners_bytes : 0);
-  auto fetch_record = [&](int t) {          // record of unit t -> its slot, by LDS-DMA (waves 0 / 1: one piece each)
+  // units in the pipeline (2 * cluster + column half; < 0: none): [0] = the one fetch_record took last ... [PIPE - 1] = the one being reduced
+  constexpr int PIPE = DEPTH + 2;
+  int u_unit[PIPE];
+#pragma unroll
+  for (int q = 0; q < PIPE; ++q) u_unit[q] = -1;
+  int32_t* l_deal = reinterpret_cast<int32_t*>(lds + a.deal_off);   // 0 .. PIPE - 2: the prologue's units, 6 / 7: the loop's
+  int entered = 0;
+  auto next_unit = [&](int deal_slot) {
+#pragma unroll
+    for (int q = PIPE - 1; q > 0; --q) u_unit[q] = u_unit[q - 1];
+    if (dynamic) {
+      u_unit[0] = __builtin_amdgcn_readfirstlane(l_deal[deal_slot]);
+    } else if (entered < n_static) {
+      u_unit[0] = lo + j + entered * per_xcd;
+      ++entered;
+    } else {
+      u_unit[0] = -1;
+    }
+  };
+  // the dealer (the workgroup's last wave): `count` units off the XCD's counter (take) into l_deal[slot0 ..] (publish).  In the loop
+  // the add is issued in one iteration and published at the top of the next, behind the wait every wave makes there anyway: the dealer
+  // never waits for the counter's round trip on its own.
+  auto take = [&](int count) {
+    unsigned base = 0;
+    if (lane == 0) base = __hip_atomic_fetch_add(a.counters + 32 * xcd, static_cast<unsigned>(count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return base;
+  };
+  auto publish = [&](unsigned taken, int count, int slot0) {
+    const unsigned base = __builtin_amdgcn_readfirstlane(taken);
+    for (int q = 0; q < count; ++q) {
+      const unsigned idx = base + q;
+      const bool ok = idx < 2u * static_cast<unsigned>(span);
+      const unsigned part = idx >= static_cast<unsigned>(span) ? 1u : 0u;
+      if (lane == 0) l_deal[slot0 + q] = ok ? static_cast<int>(((clo + idx - part * span) << 1) | part) : -1;
+    }
+  };
+  auto fetch_record = [&](int t, int unit) {   // record of unit t -> its slot, by LDS-DMA (waves 0 / 1: one piece each)
     if (wave < pieces) {
-      const unsigned cluster = static_cast<unsigned>(lo + j + t * per_xcd) >> 1;
+      const unsigned cluster = static_cast<unsigned>(unit) >> 1;
       const int word = 256 * wave + 4 * lane;
       const unsigned voff = word < words ? (cluster * static_cast<unsigned>(words) + word) * 4u : 0xFFFFFFF0u;
       rr(lds + (t % n_recs) * rec_bytes + 1024 * wave, voff);
     }
   };
-  auto issue_gathers = [&](int t) {         // this wave's share of unit t's gathers; its record is in LDS.  Returns their count
+  auto issue_gathers = [&](int t, int unit) {   // this wave's share of unit t's gathers; its record is in LDS.  Returns their count
     const int32_t* l_rec = reinterpret_cast<const int32_t*>(lds + (t % n_recs) * rec_bytes);
     unsigned char* image = images + (t % n_images) * image_bytes;
     const int n_srcs = l_rec[1];
-    const int part = (lo + j + t * per_xcd) & 1;
+    const int part = unit & 1;
     const int half = lane >> 5;
     // lane l keeps the id of row 2 (wave + n_waves (l / 2)) + l % 2: every row pair this wave fetches, one LDS read
     const int last = pad4(a.max_srcs) - 1;
@@ -278,10 +324,23 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
   // fetched in iteration it - 1 must have landed; vector-memory operations retire in order, so everything YOUNGER than that
   // record fetch may stay in flight: the previous iteration's stores and, for depth >= 2, its gathers (for depth 1 those ARE
   // the gathers of unit `it`).
-  for (int t = 0; t <= depth && t < n_my; ++t) fetch_record(t);
+  if (dynamic) {
+    if (wave == n_waves - 1) {
+      publish(take(PIPE - 1), PIPE - 1, 0);   // the prologue's units ...
+      publish(take(1), 1, 6);                 // ... and the one iteration 0 enters
+    }
+    barrier_all();
+  }
+  unsigned taken = 0;                         // the dealer's add of the iteration before
+#pragma unroll
+  for (int t = 0; t <= depth; ++t) {        // afterwards u_unit[depth - t] is unit t
+    next_unit(t);
+    if (u_unit[0] >= 0) fetch_record(t, u_unit[0]);
+  }
   barrier_all();
   int pending_gathers = 0, stores = 0;
-  for (int t = 0; t < depth && t < n_my; ++t) pending_gathers = WHATIF != 1 ? issue_gathers(t) : 0;
+#pragma unroll
+  for (int t = 0; t < depth; ++t) pending_gathers = (WHATIF != 1 && u_unit[depth - t] >= 0) ? issue_gathers(t, u_unit[depth - t]) : 0;
   if (depth == 1) pending_gathers = 0;
   // WHATIF == 9 (tools/diag only): shader-clock stamps of wave 0 around the phases of an iteration, summed per workgroup into
   // `arg` (which then is a buffer of 8 x uint64 per workgroup, not the winners): wait for gathers | barrier | issue | reduce
@@ -294,22 +353,27 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
     }
   };
   if constexpr (WHATIF == 9) stamp = __builtin_amdgcn_s_memtime();
-  for (int it = 0; it < n_my; ++it) {
+  int it = 0;
+  for (;; ++it) {
     wait_vm_all_but(pending_gathers + stores);
+    if (dynamic && it > 0 && wave == n_waves - 1) publish(taken, 1, 6 + (it & 1));   // this slot was last read two barriers ago
     lap(0);
     barrier_lds();                          // ... and everyone else's; the oldest image and the oldest record slot are free
     lap(1);
+    next_unit(6 + (it & 1));                // u_unit[0] = unit it + depth + 1, [1] = unit it + depth, [PIPE - 1] = unit it
+    if (u_unit[PIPE - 1] < 0) break;        // units come in walk order: nothing behind an empty slot
+    if (dynamic && wave == n_waves - 1) taken = take(1);   // published at the top of the next iteration
     if constexpr (DEPTH == 1) {             // the next unit's gathers first, then the record of the unit after it
-      if (it + 1 < n_my && WHATIF != 1) issue_gathers(it + 1);
-      if (it + 2 < n_my) fetch_record(it + 2);
+      if (u_unit[1] >= 0 && WHATIF != 1) issue_gathers(it + 1, u_unit[1]);
+      if (u_unit[0] >= 0) fetch_record(it + 2, u_unit[0]);
     } else {
-      if (it + depth + 1 < n_my) fetch_record(it + depth + 1);
-      pending_gathers = (it + depth < n_my && WHATIF != 1) ? issue_gathers(it + depth) : 0;
+      if (u_unit[0] >= 0) fetch_record(it + depth + 1, u_unit[0]);
+      pending_gathers = (u_unit[1] >= 0 && WHATIF != 1) ? issue_gathers(it + depth, u_unit[1]) : 0;
     }
     lap(2);
     const int32_t* l_rec = reinterpret_cast<const int32_t*>(lds + (it % n_recs) * rec_bytes);
     const unsigned char* image = images + (it % n_images) * image_bytes;
-    const int part = (lo + j + it * per_xcd) & 1;
+    const int part = u_unit[PIPE - 1] & 1;
     if constexpr (WHATIF == 2)
       stores = 0;
     else if constexpr (WHATIF >= 3 && WHATIF <= 4 && !BWD)
@@ -325,7 +389,15 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
     if (threadIdx.x == 0) {
       unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.arg) + 8 * static_cast<size_t>(blockIdx.x);
       for (int q = 0; q < 4; ++q) dbg[q] = phase[q];
-      dbg[4] = static_cast<unsigned long long>(n_my);
+      dbg[4] = static_cast<unsigned long long>(it);
+    }
+  }
+  // the last workgroup of the XCD to finish leaves the counters zero for the next launch
+  if (dynamic && threadIdx.x == 0) {
+    unsigned* done = a.counters + 32 * xcd + 16;
+    if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(per_xcd) - 1u) {
+      __hip_atomic_store(a.counters + 32 * xcd, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -353,8 +425,10 @@ inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_
     // the persistent streaming form: depth + 2 record slots + depth + 1 images per workgroup; two workgroups per CU.  Gathers run one
     // unit ahead; two units ahead (GTS_OPT_CLUSTER_RING = 2, where that fits) is kept for A/B runs: no gain measured
     const int64_t rec_slot = 1024LL * ((a.layout.words + 255) / 256), image = p.slot_bytes - p.image_off;
-    const int depth = (g_cluster_ring == 2 && WHATIF == 0 && 4 * rec_slot + 3 * image <= kMaxLds) ? 2 : 1;
-    const int64_t wg_lds = (depth + 2) * rec_slot + (depth + 1) * image;
+    const int depth = (g_cluster_ring == 2 && WHATIF == 0 && 4 * rec_slot + 3 * image + 64 <= kMaxLds) ? 2 : 1;
+    const int64_t wg_lds = (depth + 2) * rec_slot + (depth + 1) * image + 64;   // + the dealt units
+    a.deal_off = static_cast<int>(wg_lds) - 64;
+    if (g_cluster_dealing == 1) a.counters = nullptr;   // static round-robin dealing (A/B runs)
     if (wg_lds > kMaxLds || a.layout.words > 512) return GTS_ERR_SHAPE;
     a.ring = depth;
     const int waves = g_cluster_consumers > 0 ? std::min(16, g_cluster_consumers) : (BWD ? 12 : 16);
@@ -560,7 +634,7 @@ inline bool bad_cluster_shape(int64_t n_clusters, int32_t max_rows, int32_t max_
 extern "C" int32_t gts_spmm_max_fwd_cluster_f32(const int32_t* rec, int64_t n_clusters, int32_t max_rows, int32_t max_srcs,
                                                 int32_t loc_words, const float* x, float* out, void* arg,
                                                 int32_t arg_bytes, int32_t relu_input, int64_t n_rows, int64_t n_feat,
-                                                void* stream) {
+                                                uint32_t* counters, void* stream) {
   using namespace gts;
   if (!rec || !x || !out || (arg_bytes != 0 && !arg)) return GTS_ERR_NULL;
   if (bad_cluster_shape(n_clusters, max_rows, max_srcs, loc_words, false, n_rows, n_feat)) return GTS_ERR_SHAPE;
@@ -569,7 +643,7 @@ extern "C" int32_t gts_spmm_max_fwd_cluster_f32(const int32_t* rec, int64_t n_cl
   ClusterArgs a{};
   a.rec = rec, a.layout = rec_layout(max_rows, max_srcs, loc_words, false);
   a.n_clusters = static_cast<int>(n_clusters), a.max_srcs = max_srcs;
-  a.table = x, a.out = out, a.arg = static_cast<uint8_t*>(arg);
+  a.table = x, a.out = out, a.arg = static_cast<uint8_t*>(arg), a.counters = counters;
   a.table_bytes = static_cast<unsigned>(n_rows * kF * 4);
   a.relu_input = relu_input, a.nt = g_cluster_nt < 0 ? 1 : g_cluster_nt;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -578,7 +652,7 @@ extern "C" int32_t gts_spmm_max_fwd_cluster_f32(const int32_t* rec, int64_t n_cl
 
 extern "C" int32_t gts_spmm_max_bwd_cluster_f32(const int32_t* rec, int64_t n_clusters, int32_t max_rows, int32_t max_srcs,
                                                 int32_t loc_words, const float* gout, const void* arg, int32_t arg_bytes,
-                                                float* gx, int64_t n_rows, int64_t n_feat, void* stream) {
+                                                float* gx, int64_t n_rows, int64_t n_feat, uint32_t* counters, void* stream) {
   using namespace gts;
   if (!rec || !gout || !arg || !gx) return GTS_ERR_NULL;
   if (bad_cluster_shape(n_clusters, max_rows, max_srcs, loc_words, true, n_rows, n_feat)) return GTS_ERR_SHAPE;
@@ -587,7 +661,7 @@ extern "C" int32_t gts_spmm_max_bwd_cluster_f32(const int32_t* rec, int64_t n_cl
   ClusterArgs a{};
   a.rec = rec, a.layout = rec_layout(max_rows, max_srcs, loc_words, true);
   a.n_clusters = static_cast<int>(n_clusters), a.max_srcs = max_srcs;
-  a.table = gout, a.winners = static_cast<const uint8_t*>(arg), a.out = gx;
+  a.table = gout, a.winners = static_cast<const uint8_t*>(arg), a.out = gx, a.counters = counters;
   a.table_bytes = static_cast<unsigned>(n_rows * kF * 4), a.winners_bytes = static_cast<unsigned>(n_rows * kF);
   a.nt = g_cluster_nt < 0 ? 1 : g_cluster_nt;
   return launch_cluster<true, 1>(a, max_rows, loc_words, static_cast<hipStream_t>(stream));

@@ -32,6 +32,7 @@ struct FwdPlan {
   int64_t m[kMaxLayers], arg[kMaxLayers], out[kMaxLayers], bits[kMaxLayers];   // byte offsets; -1 = absent
   int64_t p[2];
   int64_t wp[kMaxLayers][3];   // w_pool / w_self / w_neigh in fragment order (gts_pack_weights_f32); -1 = read as stored
+  int64_t counters;            // unit counters of the clustered K1 launches (zeroed once per call; every launch leaves them zero)
   int64_t total;
 };
 
@@ -58,6 +59,7 @@ inline FwdPlan plan_forward(int64_t n, const int64_t* w, int n_layers, bool trai
     p.wp[i][1] = packs(w[i + 1]) ? take(4 * gts_packed_weight_floats(w[i + 1], w[i])) : -1;
     p.wp[i][2] = packs(w[i + 1]) ? take(4 * gts_packed_weight_floats(w[i + 1], w[i])) : -1;
   }
+  p.counters = take(4 * GTS_CLUSTER_COUNTER_WORDS);
   p.total = at;
   return p;
 }
@@ -82,6 +84,7 @@ struct BwdPlan {
   int64_t g[kMaxLayers], gp[kMaxLayers];   // g[i] (i >= 1): gradient w.r.t. layer i-1's pre-activation output; gp[i]: w.r.t. fc_pool's
   int64_t gm[2];
   int64_t workspace, workspace_bytes;
+  int64_t counters;                        // unit counters of the clustered K2 launches (as FwdPlan::counters)
   int64_t total;
 };
 
@@ -126,6 +129,7 @@ inline BwdPlan plan_backward(int64_t n, const int64_t* w, int n_layers, int flag
         ws = std::max(ws, gts_linear_bwd_weight_workspace(n, gk.n, gk.k, std::min(kMaxWgradProblems, gk.count - first)));
   p.workspace_bytes = ws;
   p.workspace = take(ws);
+  p.counters = take(4 * GTS_CLUSTER_COUNTER_WORDS);
   p.total = at;
   return p;
 }
@@ -167,6 +171,11 @@ extern "C" int32_t gts_sage_pool_stack_fwd_f32(const int32_t* indptr, const int3
   if (n_rows == 0) return GTS_OK;
   char* base = static_cast<char*>(arena);
   auto f32 = [&](int64_t off) { return reinterpret_cast<float*>(base + off); };
+  uint32_t* counters = nullptr;   // unit counters of the clustered K1 launches: zeroed once here, every launch leaves them zero
+  if (sched_rec != nullptr) {
+    counters = reinterpret_cast<uint32_t*>(base + plan.counters);
+    if (hipMemsetAsync(counters, 0, 4 * GTS_CLUSTER_COUNTER_WORDS, static_cast<hipStream_t>(stream)) != hipSuccess) return GTS_ERR_SHAPE;
+  }
   // the weights the panel GEMMs will read, in fragment order: one launch per weight shape (the weights change once per
   // optimizer step; 19 matrices of 256 KiB at C2)
   {
@@ -212,7 +221,7 @@ extern "C" int32_t gts_sage_pool_stack_fwd_f32(const int32_t* indptr, const int3
     const int ab = train ? arg_bytes : 0;
     if (sched_rec != nullptr && fin == 256 && ab != 4 && n_rows * 1024 < (1LL << 32)) {
       GTS_TRY(gts_spmm_max_fwd_cluster_f32(sched_rec, sched_clusters, sched_rows, sched_srcs, sched_loc_words, p, m, arg, ab,
-                                           1, n_rows, fin, stream));
+                                           1, n_rows, fin, counters, stream));
     } else {
       GTS_TRY(gts_spmm_max_fwd_f32(indptr, indices, p, m, arg, ab, 1, n_rows, fin, stream));
     }
@@ -268,6 +277,11 @@ extern "C" int32_t gts_sage_pool_stack_bwd_f32(const int32_t* t_indptr, const in
   const char* acts = static_cast<const char*>(fwd_arena);
   char* base = static_cast<char*>(scratch);
   auto f32 = [&](int64_t off) { return reinterpret_cast<float*>(base + off); };
+  uint32_t* counters = nullptr;   // unit counters of the clustered K2 launches (as in the forward call)
+  if (sched_rec != nullptr) {
+    counters = reinterpret_cast<uint32_t*>(base + plan.counters);
+    if (hipMemsetAsync(counters, 0, 4 * GTS_CLUSTER_COUNTER_WORDS, static_cast<hipStream_t>(stream)) != hipSuccess) return GTS_ERR_SHAPE;
+  }
   auto act = [&](int64_t off) { return reinterpret_cast<const float*>(acts + off); };
   auto input_of = [&](int i) { return i == 0 ? x : act(fwd.out[i - 1]); };
 
@@ -338,7 +352,7 @@ extern "C" int32_t gts_sage_pool_stack_bwd_f32(const int32_t* t_indptr, const in
     float* gp = f32(plan.gp[i]);   // ReLU'(p) is already in the winner record
     if (sched_rec != nullptr && fin == 256 && arg_bytes == 1 && n_rows * 1024 < (1LL << 32)) {
       GTS_TRY(gts_spmm_max_bwd_cluster_f32(sched_rec, sched_clusters, sched_rows, sched_srcs, sched_loc_words, gm, arg, 1, gp,
-                                           n_rows, fin, stream));
+                                           n_rows, fin, counters, stream));
     } else {
       GTS_TRY(gts_spmm_max_bwd_f32(t_indptr, t_indices, t_slot, gm, arg, arg_bytes, nullptr, gp, n_rows, fin, stream));
     }

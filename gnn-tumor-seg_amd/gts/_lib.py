@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GTS_LIB_PATH: another build of the same library (A/B runs of two builds in one session, tools/); the default is the in-tree build
 LIB_PATH = os.environ.get("GTS_LIB_PATH") or os.path.join(_HERE, "libgts_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "gts_hip.h")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _p = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -28,8 +28,8 @@ SIGNATURES = {
     "gts_cluster_record_words": [_i32, _i32, _i32, _i32],
     "gts_cluster_schedule": [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p],
     "gts_cluster_lds_bytes": [_i32, _i32, _i32, _i32],
-    "gts_spmm_max_fwd_cluster_f32": [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _i32, _i64, _i64, _p],
-    "gts_spmm_max_bwd_cluster_f32": [_p, _i64, _i32, _i32, _i32, _p, _p, _i32, _p, _i64, _i64, _p],
+    "gts_spmm_max_fwd_cluster_f32": [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _i32, _i64, _i64, _p, _p],
+    "gts_spmm_max_bwd_cluster_f32": [_p, _i64, _i32, _i32, _i32, _p, _p, _i32, _p, _i64, _i64, _p, _p],
     "gts_spmm_sum_f32": [_p, _p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _p],
     "gts_gat_fwd_f32": [_p, _p, _p, _p, _p, _f32, _p, _p, _i32, _p, _p, _i64, _i64, _i64, _p],
     "gts_gat_scores_f32": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p],

@@ -38,6 +38,20 @@ def _f32(*tensors):
             raise _lib.GtsError(f"gts kernels are fp32: got {t.dtype}")
 
 
+_cluster_counters = {}
+
+
+def cluster_counters(device):
+    """The unit counters of the clustered K1 / K2 kernels (include/gts_hip.h: GTS_CLUSTER_COUNTER_WORDS zero words that every launch
+    leaves zero): one buffer per (device, stream), zeroed once."""
+    key = (device, current_stream())
+    buf = _cluster_counters.get(key)
+    if buf is None:
+        buf = torch.zeros(256, dtype=torch.int32, device=device)
+        _cluster_counters[key] = buf
+    return buf
+
+
 # ---------------------------------------------------------------- raw kernel calls
 def spmm_max_fwd(g, x, want_arg=True, relu_input=False):
     """K1.  x [N,F] -> (out [N,F], arg [N,F] slot ids or None).  relu_input: x is a ReLU output;
@@ -61,7 +75,7 @@ def spmm_max_fwd(g, x, want_arg=True, relu_input=False):
         def launch():
             return lib.gts_spmm_max_fwd_cluster_f32(ptr(ds.packed), h.n_clusters, h.limits[0], h.limits[1], h.loc_words,
                                                     ptr(x), ptr(out), ptr(arg), ab, 1 if relu_input else 0, n, f,
-                                                    current_stream())
+                                                    ptr(cluster_counters(x.device)), current_stream())
     else:
         def launch():
             return lib.gts_spmm_max_fwd_f32(ptr(d.indptr), ptr(d.indices), ptr(x), ptr(out), ptr(arg),
@@ -105,7 +119,8 @@ def spmm_max_bwd(g, gout, arg, relu_src=None):
 
         def launch():
             return lib.gts_spmm_max_bwd_cluster_f32(ptr(ds.packed), h.n_clusters, h.limits[0], h.limits[1], h.loc_words,
-                                                    ptr(gout), ptr(arg), 1, ptr(gx), n, f, current_stream())
+                                                    ptr(gout), ptr(arg), 1, ptr(gx), n, f, ptr(cluster_counters(gout.device)),
+                                                    current_stream())
     else:
         def launch():
             return lib.gts_spmm_max_bwd_f32(ptr(d.t_indptr), ptr(d.t_indices), ptr(d.t_slot), ptr(gout),

@@ -141,17 +141,24 @@ def test_cluster_entry_points_reject_bad_arguments():
     out = torch.empty_like(x)
     P = lambda t: t.data_ptr()      # noqa: E731
     rec, lim = P(ds.packed), (h.limits[0], h.limits[1], h.loc_words)
-    assert lib.gts_spmm_max_fwd_cluster_f32(rec, h.n_clusters, *lim, P(x), P(out), None, 0, 0, g.n, 128, None) == -2    # F != 256
-    assert lib.gts_spmm_max_fwd_cluster_f32(rec, h.n_clusters, *lim, P(x), P(out), None, 1, 0, g.n, 256, None) == -1    # arg missing
-    assert lib.gts_spmm_max_fwd_cluster_f32(rec, h.n_clusters, *lim, P(x), P(out), None, 4, 0, g.n, 256, None) == -1
-    assert lib.gts_spmm_max_fwd_cluster_f32(rec, h.n_clusters, *lim, None, P(out), None, 0, 0, g.n, 256, None) == -1
+    assert lib.gts_spmm_max_fwd_cluster_f32(rec, h.n_clusters, *lim, P(x), P(out), None, 0, 0, g.n, 128, None, None) == -2    # F != 256
+    assert lib.gts_spmm_max_fwd_cluster_f32(rec, h.n_clusters, *lim, P(x), P(out), None, 1, 0, g.n, 256, None, None) == -1    # arg missing
+    assert lib.gts_spmm_max_fwd_cluster_f32(rec, h.n_clusters, *lim, P(x), P(out), None, 4, 0, g.n, 256, None, None) == -1
+    assert lib.gts_spmm_max_fwd_cluster_f32(rec, h.n_clusters, *lim, None, P(out), None, 0, 0, g.n, 256, None, None) == -1
     assert lib.gts_spmm_max_fwd_cluster_f32(rec, h.n_clusters, h.limits[0], 300, h.loc_words, P(x), P(out), None, 0, 0,
-                                            g.n, 256, None) == -2                                          # byte-indexed neighbours
-    assert lib.gts_spmm_max_fwd_cluster_f32(rec, h.n_clusters, *lim, P(x), P(out), None, 0, 0, g.n, 256, None) == 0
+                                            g.n, 256, None, None) == -2                                          # byte-indexed neighbours
+    assert lib.gts_spmm_max_fwd_cluster_f32(rec, h.n_clusters, *lim, P(x), P(out), None, 0, 0, g.n, 256, None, None) == 0   # no counters: static dealing
+    want = out.clone()
+    counters = torch.zeros(256, dtype=torch.int32, device=DEV)
+    for _ in range(3):        # the launch leaves its counters zero: the same buffer serves the next one
+        out.fill_(float("nan"))
+        assert lib.gts_spmm_max_fwd_cluster_f32(rec, h.n_clusters, *lim, P(x), P(out), None, 0, 0, g.n, 256, P(counters), None) == 0
+        assert torch.equal(out, want)
+        assert int(counters.abs().sum()) == 0
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("options", [{10: 2}, {12: 4}, {12: 6, 11: 1}, {11: 3}, {12: 16, 11: 3, 10: 2}, {8: 0}])
+@pytest.mark.parametrize("options", [{10: 2}, {12: 4}, {12: 6, 11: 1}, {11: 3}, {12: 16, 11: 3, 10: 2}, {8: 0}, {18: 1}, {18: 1, 10: 2}])
 def test_every_launch_geometry_gives_the_same_bits(options):
     """Waves per workgroup, persistent workgroups per CU (2 by default, 3 for short backward launches), gathers one or two
     units ahead, streaming stores: tuning choices of the persistent form — results must not depend on them."""
