@@ -214,7 +214,7 @@ __device__ __forceinline__ void gather_winner_halves(const Dma& dma, int part, u
 // only) share the x-th eighth of the units and take them round-robin.  LDS: three record slots, two images.
 // WHATIF != 0 only in the timing experiments of tools/diag (wrong results): 1 = no row gathers, 2 = no reduction and
 // no stores, 3 = no stores, 4 = stores without the reduction (K1).
-template <bool BWD, int ARGB, int WHATIF = 0, int DEPTH = 1>
+template <bool BWD, int ARGB, int WHATIF = 0, int DEPTH = 1, bool DEAL = false>   // DEAL: units dealt off the XCD's counter (a.counters)
 // Two workgroups per CU: 16 waves each for K1 (<= 64 registers), 12 for K2 (its 68 registers: 6 waves per SIMD).  With 8 waves
 // the reduction of a unit is latency-bound (lattice, 8 graphs: 67.6 / 72.2 us against 63.9 / 67.8; k-NN graphs of mean
 // degree 7 - 10: 78 - 144 us against 65 - 96, profiles/r03_cluster_other_graphs.log).
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
   // t-th.  DYNAMIC (the default): the XCD's workgroups take their units off one counter, in the order "every cluster of the XCD's span for
   // the left half, then for the right half" — the units in flight stay neighbours in that walk whatever each workgroup's pace, and their
   // halo rows meet in the XCD's L2 (a workgroup one unit behind under static dealing is per_xcd units behind in the walk).
-  const bool dynamic = a.counters != nullptr;
+  constexpr bool dynamic = DEAL;           // a compile-time choice: as a run-time one it cost both forms spilled registers
   const int n_static = lo + j < hi ? (hi - lo - j + per_xcd - 1) / per_xcd : 0;   // units lo + j + t * per_xcd, t < n_static
   if (!dynamic && n_static == 0) return;
   const int clo = static_cast<int>(static_cast<long long>(a.n_clusters) * xcd / 8);
@@ -248,21 +248,28 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
   const RawDma rw(a.winners, BWD ? a.winners_bytes : 0);
   // units in the pipeline (2 * cluster + column half; < 0: none): [0] = the one fetch_record took last ... [PIPE - 1] = the one being reduced
   constexpr int PIPE = DEPTH + 2;
-  int u_unit[PIPE];
+  // (kept only by the dealt form: under static dealing unit t is a closed form — its pipeline as registers cost spills)
+  int u_unit[dynamic ? PIPE : 1];
 #pragma unroll
-  for (int q = 0; q < PIPE; ++q) u_unit[q] = -1;
+  for (int q = 0; q < (dynamic ? PIPE : 1); ++q) u_unit[q] = -1;
   int32_t* l_deal = reinterpret_cast<int32_t*>(lds + a.deal_off);   // 0 .. PIPE - 2: the prologue's units, 6 / 7: the loop's
-  int entered = 0;
+  // l_deal holds the counter's values as taken; every wave turns one into its unit (2 * cluster + half; < 0: the span is exhausted)
   auto next_unit = [&](int deal_slot) {
+    if constexpr (dynamic) {
 #pragma unroll
-    for (int q = PIPE - 1; q > 0; --q) u_unit[q] = u_unit[q - 1];
-    if (dynamic) {
-      u_unit[0] = __builtin_amdgcn_readfirstlane(l_deal[deal_slot]);
-    } else if (entered < n_static) {
-      u_unit[0] = lo + j + entered * per_xcd;
-      ++entered;
+      for (int q = PIPE - 1; q > 0; --q) u_unit[q] = u_unit[q - 1];
+      const unsigned idx = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(l_deal[deal_slot]));
+      const unsigned part = idx >= static_cast<unsigned>(span) ? 1u : 0u;
+      u_unit[0] = idx < 2u * static_cast<unsigned>(span) ? static_cast<int>(((clo + idx - part * span) << 1) | part) : -1;
+    }
+  };
+  // stage k of the pipeline while unit `newest` is the one fetch_record takes: its unit, or < 0
+  auto unit_at = [&](int k, int newest) {
+    if constexpr (dynamic) {
+      return u_unit[k];
     } else {
-      u_unit[0] = -1;
+      const int t = newest - k;
+      return t < n_static ? lo + j + t * per_xcd : -1;
     }
   };
   // the dealer (the workgroup's last wave): `count` units off the XCD's counter (take) into l_deal[slot0 ..] (publish).  In the loop
@@ -274,12 +281,8 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
     return base;
   };
   auto publish = [&](unsigned taken, int count, int slot0) {
-    const unsigned base = __builtin_amdgcn_readfirstlane(taken);
-    for (int q = 0; q < count; ++q) {
-      const unsigned idx = base + q;
-      const bool ok = idx < 2u * static_cast<unsigned>(span);
-      const unsigned part = idx >= static_cast<unsigned>(span) ? 1u : 0u;
-      if (lane == 0) l_deal[slot0 + q] = ok ? static_cast<int>(((clo + idx - part * span) << 1) | part) : -1;
+    if (lane == 0) {
+      for (int q = 0; q < count; ++q) l_deal[slot0 + q] = static_cast<int>(taken + q);
     }
   };
   auto fetch_record = [&](int t, int unit) {   // record of unit t -> its slot, by LDS-DMA (waves 0 / 1: one piece each)
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
   // fetched in iteration it - 1 must have landed; vector-memory operations retire in order, so everything YOUNGER than that
   // record fetch may stay in flight: the previous iteration's stores and, for depth >= 2, its gathers (for depth 1 those ARE
   // the gathers of unit `it`).
-  if (dynamic) {
+  if constexpr (dynamic) {
     if (wave == n_waves - 1) {
       publish(take(PIPE - 1), PIPE - 1, 0);   // the prologue's units ...
       publish(take(1), 1, 6);                 // ... and the one iteration 0 enters
@@ -333,14 +336,14 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
   }
   unsigned taken = 0;                         // the dealer's add of the iteration before
 #pragma unroll
-  for (int t = 0; t <= depth; ++t) {        // afterwards u_unit[depth - t] is unit t
+  for (int t = 0; t <= depth; ++t) {        // afterwards stage depth - t holds unit t
     next_unit(t);
-    if (u_unit[0] >= 0) fetch_record(t, u_unit[0]);
+    if (unit_at(0, t) >= 0) fetch_record(t, unit_at(0, t));
   }
   barrier_all();
   int pending_gathers = 0, stores = 0;
 #pragma unroll
-  for (int t = 0; t < depth; ++t) pending_gathers = (WHATIF != 1 && u_unit[depth - t] >= 0) ? issue_gathers(t, u_unit[depth - t]) : 0;
+  for (int t = 0; t < depth; ++t) pending_gathers = (WHATIF != 1 && unit_at(depth - t, depth) >= 0) ? issue_gathers(t, unit_at(depth - t, depth)) : 0;
   if (depth == 1) pending_gathers = 0;
   // WHATIF == 9 (tools/diag only): shader-clock stamps of wave 0 around the phases of an iteration, summed per workgroup into
   // `arg` (which then is a buffer of 8 x uint64 per workgroup, not the winners): wait for gathers | barrier | issue | reduce
@@ -354,26 +357,34 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
   };
   if constexpr (WHATIF == 9) stamp = __builtin_amdgcn_s_memtime();
   int it = 0;
-  for (;; ++it) {
+  for (; dynamic || it < n_static; ++it) {
     wait_vm_all_but(pending_gathers + stores);
-    if (dynamic && it > 0 && wave == n_waves - 1) publish(taken, 1, 6 + (it & 1));   // this slot was last read two barriers ago
+    if constexpr (dynamic) {
+      if (it > 0 && wave == n_waves - 1) publish(taken, 1, 6 + (it & 1));   // this slot was last read two barriers ago
+    }
     lap(0);
     barrier_lds();                          // ... and everyone else's; the oldest image and the oldest record slot are free
     lap(1);
-    next_unit(6 + (it & 1));                // u_unit[0] = unit it + depth + 1, [1] = unit it + depth, [PIPE - 1] = unit it
-    if (u_unit[PIPE - 1] < 0) break;        // units come in walk order: nothing behind an empty slot
-    if (dynamic && wave == n_waves - 1) taken = take(1);   // published at the top of the next iteration
+    next_unit(6 + (it & 1));                // stage 0 = unit it + depth + 1, stage 1 = unit it + depth, stage PIPE - 1 = unit it
+    const int newest = it + depth + 1;
+    const int unit_now = unit_at(PIPE - 1, newest);
+    if constexpr (dynamic) {
+      if (unit_now < 0) break;              // units come in walk order: nothing behind an empty slot
+    }
+    if constexpr (dynamic) {
+      if (wave == n_waves - 1) taken = take(1);   // published at the top of the next iteration
+    }
     if constexpr (DEPTH == 1) {             // the next unit's gathers first, then the record of the unit after it
-      if (u_unit[1] >= 0 && WHATIF != 1) issue_gathers(it + 1, u_unit[1]);
-      if (u_unit[0] >= 0) fetch_record(it + 2, u_unit[0]);
+      if (unit_at(1, newest) >= 0 && WHATIF != 1) issue_gathers(it + 1, unit_at(1, newest));
+      if (unit_at(0, newest) >= 0) fetch_record(it + 2, unit_at(0, newest));
     } else {
-      if (u_unit[0] >= 0) fetch_record(it + depth + 1, u_unit[0]);
-      pending_gathers = (u_unit[1] >= 0 && WHATIF != 1) ? issue_gathers(it + depth, u_unit[1]) : 0;
+      if (unit_at(0, newest) >= 0) fetch_record(it + depth + 1, unit_at(0, newest));
+      pending_gathers = (unit_at(1, newest) >= 0 && WHATIF != 1) ? issue_gathers(it + depth, unit_at(1, newest)) : 0;
     }
     lap(2);
     const int32_t* l_rec = reinterpret_cast<const int32_t*>(lds + (it % n_recs) * rec_bytes);
     const unsigned char* image = images + (it % n_images) * image_bytes;
-    const int part = u_unit[PIPE - 1] & 1;
+    const int part = unit_now & 1;
     if constexpr (WHATIF == 2)
       stores = 0;
     else if constexpr (WHATIF >= 3 && WHATIF <= 4 && !BWD)
@@ -393,7 +404,7 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
     }
   }
   // the last workgroup of the XCD to finish leaves the counters zero for the next launch
-  if (dynamic && threadIdx.x == 0) {
+  if (dynamic && threadIdx.x == 0) {   // (compile-time)
     unsigned* done = a.counters + 32 * xcd + 16;
     if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(per_xcd) - 1u) {
       __hip_atomic_store(a.counters + 32 * xcd, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -428,7 +439,11 @@ inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_
     const int depth = (g_cluster_ring == 2 && WHATIF == 0 && 4 * rec_slot + 3 * image + 64 <= kMaxLds) ? 2 : 1;
     const int64_t wg_lds = (depth + 2) * rec_slot + (depth + 1) * image + 64;   // + the dealt units
     a.deal_off = static_cast<int>(wg_lds) - 64;
-    if (g_cluster_dealing == 1) a.counters = nullptr;   // static round-robin dealing (A/B runs)
+    // Static dealing unless asked (GTS_OPT_CLUSTER_DEALING 1): dealt units bring the fabric traffic to its compulsory figure (32 graphs per
+    // GPU: 1.31 / 1.18 -> 1.05 / 1.03 x) but these kernels are not bound by it, and at their register caps (64 / 80) the dealt form spills 3 - 5
+    // registers inside the unit loop — scratch loads that also count in the counted vmcnt waits: K1 68 -> 85 us at 8 graphs, K2 65 -> 71, 35.9 ->
+    // 39.2 at C2 (profiles/r04/k12_dealing_ab.log).  The GAT kernels (registers to spare, memory-bound) deal by default.
+    if (g_cluster_dealing != 1) a.counters = nullptr;
     if (wg_lds > kMaxLds || a.layout.words > 512) return GTS_ERR_SHAPE;
     a.ring = depth;
     const int waves = g_cluster_consumers > 0 ? std::min(16, g_cluster_consumers) : (BWD ? 12 : 16);
@@ -441,16 +456,21 @@ inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_
     const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g_cluster_per_cu > 0 ? g_cluster_per_cu : auto_per_cu, kMaxLds / wg_lds)));
     int64_t grid = static_cast<int64_t>(device_cus()) * per_cu;
     grid = std::max<int64_t>(8, std::min(grid, (units + 7) / 8 * 8)) / 8 * 8;
-    static const bool once = (allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF, 1>),
-                              allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF == 0 ? 0 : WHATIF, WHATIF == 0 ? 2 : 1>), true);
+    static const bool once = (allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF, 1, false>),
+                              allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF, 1, true>),
+                              allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF == 0 ? 0 : WHATIF, WHATIF == 0 ? 2 : 1, false>),
+                              allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF == 0 ? 0 : WHATIF, WHATIF == 0 ? 2 : 1, true>), true);
     (void)once;
+    const dim3 g3(static_cast<unsigned>(grid));
     if constexpr (WHATIF == 0) {
       if (depth == 2) {
-        spmm_cluster_stream_kernel<BWD, ARGB, 0, 2><<<dim3(static_cast<unsigned>(grid)), waves * kWave, wg_lds, st>>>(a);
+        if (a.counters != nullptr) spmm_cluster_stream_kernel<BWD, ARGB, 0, 2, true><<<g3, waves * kWave, wg_lds, st>>>(a);
+        else spmm_cluster_stream_kernel<BWD, ARGB, 0, 2, false><<<g3, waves * kWave, wg_lds, st>>>(a);
         return launch_status();
       }
     }
-    spmm_cluster_stream_kernel<BWD, ARGB, WHATIF, 1><<<dim3(static_cast<unsigned>(grid)), waves * kWave, wg_lds, st>>>(a);
+    if (a.counters != nullptr) spmm_cluster_stream_kernel<BWD, ARGB, WHATIF, 1, true><<<g3, waves * kWave, wg_lds, st>>>(a);
+    else spmm_cluster_stream_kernel<BWD, ARGB, WHATIF, 1, false><<<g3, waves * kWave, wg_lds, st>>>(a);
     return launch_status();
   }
 }

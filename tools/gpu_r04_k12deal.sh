@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 600 python -m pytest tests/test_gpu_cluster.py tests/test_gpu_stack.py tests/test_gpu_kernels.py -m gpu -x -q > $OUT/pytest.log 2>&1
 echo "pytest rc=$?"; tail -2 $OUT/pytest.log
 grep -q " passed" $OUT/pytest.log || exit 1
-for opt in "18=1" "18=0" "18=1" "18=0"; do
+for opt in "18=0" "18=1" "18=0" "18=1"; do
   for cfg in "--steps 20 --warmup 5 --blocks 10" "--config c4 --steps 10 --warmup 3 --blocks 5" "--graphs-per-gpu 32 --steps 5 --warmup 2 --blocks 3"; do
     GTS_OPTIONS="$opt" timeout -k 10 300 python bench.py $cfg --no-cpu-baseline > $OUT/b.json 2> $OUT/b.err || { tail -5 $OUT/b.err; exit 1; }
     python - $OUT/b.json "$opt $cfg" <<'PY' | tee -a $OUT/bench.log
