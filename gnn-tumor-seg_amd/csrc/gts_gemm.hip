@@ -1528,7 +1528,7 @@ extern "C" int32_t gts_set_option(int32_t option, int32_t value) {
     case GTS_OPT_GAT_CLUSTER_WAVES: gts::g_gat_cluster_waves = value; return GTS_OK;
     case GTS_OPT_GAT_CLUSTER_GROUP: gts::g_gat_cluster_group = value; return GTS_OK;
     case GTS_OPT_CLUSTER_DEALING:
-      if (value != 0 && value != 1) return GTS_ERR_ARGKIND;
+      if (value < 0 || value > 2) return GTS_ERR_ARGKIND;
       gts::g_cluster_dealing = value;
       return GTS_OK;
     case GTS_OPT_GAT_CLUSTER_DEALING:

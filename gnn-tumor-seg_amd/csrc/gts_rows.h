@@ -148,7 +148,7 @@ inline int g_gat_walk = 1;           // K5-K8: 1 = head-major walk over the (nod
 inline int g_cluster_ring = 0;       // form 0: units the gathers run ahead (0 = automatic: 2 if it fits half a CU's LDS, else 1); form 2: ring slots
 inline int g_cluster_per_cu = 0;     // persistent workgroups per CU (0 = automatic)
 inline int g_gat_cluster_waves = 0;  // clustered GAT kernels: waves per workgroup (0 = default)
-inline int g_cluster_dealing = 0;      // clustered K1 / K2: 0 = static round-robin dealing (default), 1 = units dealt off the caller's counters
+inline int g_cluster_dealing = 0;      // clustered K1 / K2: 0 = automatic, 1 = units dealt off the caller's counters, 2 = static round-robin
 inline int g_gat_cluster_dealing = 0;  // clustered GAT kernels: 0 = units dealt off a counter per XCD (default), 1 = static round-robin
 inline int g_gat_cluster_group = 0;  // clustered GAT kernels: clusters walked together through all their slices (0 = the whole span of an XCD)
 inline int g_cluster_consumers = 0;  // form 0: waves per workgroup; form 2: consumer waves (0 = automatic)

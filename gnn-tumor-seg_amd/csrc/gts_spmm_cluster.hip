@@ -82,17 +82,35 @@ __device__ __forceinline__ int reduce_max_rows(const ClusterArgs& a, const int32
       const uint2 w = loc[mine_too ? c0 + c : c0];
       for_count(min(8, deg_w - 8 * c), [&](auto cnt_c) {
         constexpr int CNT = decltype(cnt_c)::value;
-        float4 val[CNT];
+        // at most six of a chunk's rows in registers at a time (a seventh and eighth follow): 24 instead of 32 value registers at this
+        // kernel's cap of 64, which the form that deals its units needs for its own state
+        constexpr int FIRST = CNT > 6 ? 6 : CNT;
+        float4 val[FIRST];
 #pragma unroll
-        for (int q = 0; q < CNT; ++q) val[q] = *reinterpret_cast<const float4*>(mine + chunk_byte(w, q) * kHalfBytes);
+        for (int q = 0; q < FIRST; ++q) val[q] = *reinterpret_cast<const float4*>(mine + chunk_byte(w, q) * kHalfBytes);
 #pragma unroll
-        for (int q = 0; q < CNT; ++q) {
+        for (int q = 0; q < FIRST; ++q) {
           const float v4[4] = {val[q].x, val[q].y, val[q].z, val[q].w};
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const bool up = mine_too && best[t] < v4[t];
             best[t] = up ? v4[t] : best[t];
             slot[t] = up ? 8 * c + q : slot[t];
+          }
+        }
+        if constexpr (CNT > FIRST) {
+          float4 rest[CNT - FIRST];
+#pragma unroll
+          for (int q = FIRST; q < CNT; ++q) rest[q - FIRST] = *reinterpret_cast<const float4*>(mine + chunk_byte(w, q) * kHalfBytes);
+#pragma unroll
+          for (int q = FIRST; q < CNT; ++q) {
+            const float v4[4] = {rest[q - FIRST].x, rest[q - FIRST].y, rest[q - FIRST].z, rest[q - FIRST].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const bool up = mine_too && best[t] < v4[t];
+              best[t] = up ? v4[t] : best[t];
+              slot[t] = up ? 8 * c + q : slot[t];
+            }
           }
         }
       });
@@ -145,22 +163,30 @@ __device__ __forceinline__ int reduce_winner_rows(const ClusterArgs& a, const in
         const uint2 w = loc[c0], tg = tag[c0];
         for_count(deg_w, [&](auto cnt_c) {
           constexpr int CNT = decltype(cnt_c)::value;
-          float4 g[CNT];
-          uint32_t win[CNT];
+          // at most six of a chunk's rows in registers at a time (30 instead of 40 at this kernel's cap of 80: room for the state of the form
+          // that deals its units); the sums keep their order
+          constexpr int FIRST = CNT > 6 ? 6 : CNT;
+          auto group = [&](auto q0_c, auto n_c) {
+            constexpr int Q0 = decltype(q0_c)::value, N = decltype(n_c)::value;
+            float4 g[N];
+            uint32_t win[N];
 #pragma unroll
-          for (int q = 0; q < CNT; ++q) {
-            const unsigned s = chunk_byte(w, q);
-            g[q] = *reinterpret_cast<const float4*>(my_g + s * kHalfBytes);
-            win[q] = *reinterpret_cast<const uint32_t*>(my_w + s * kArgHalfBytes);
-          }
+            for (int q = 0; q < N; ++q) {
+              const unsigned s = chunk_byte(w, Q0 + q);
+              g[q] = *reinterpret_cast<const float4*>(my_g + s * kHalfBytes);
+              win[q] = *reinterpret_cast<const uint32_t*>(my_w + s * kArgHalfBytes);
+            }
 #pragma unroll
-          for (int q = 0; q < CNT; ++q) {
-            const unsigned want = chunk_byte(tg, q);
-            acc[0] += (win[q] & 0xFF) == want ? g[q].x : 0.0f;
-            acc[1] += ((win[q] >> 8) & 0xFF) == want ? g[q].y : 0.0f;
-            acc[2] += ((win[q] >> 16) & 0xFF) == want ? g[q].z : 0.0f;
-            acc[3] += (win[q] >> 24) == want ? g[q].w : 0.0f;
-          }
+            for (int q = 0; q < N; ++q) {
+              const unsigned want = chunk_byte(tg, Q0 + q);
+              acc[0] += (win[q] & 0xFF) == want ? g[q].x : 0.0f;
+              acc[1] += ((win[q] >> 8) & 0xFF) == want ? g[q].y : 0.0f;
+              acc[2] += ((win[q] >> 16) & 0xFF) == want ? g[q].z : 0.0f;
+              acc[3] += (win[q] >> 24) == want ? g[q].w : 0.0f;
+            }
+          };
+          group(IC<0>{}, IC<FIRST>{});
+          if constexpr (CNT > FIRST) group(IC<FIRST>{}, IC<CNT - FIRST>{});
         });
       }
     } else {
@@ -169,22 +195,28 @@ __device__ __forceinline__ int reduce_winner_rows(const ClusterArgs& a, const in
         const uint2 w = loc[at], tg = tag[at];
         for_count(min(8, deg_w - 8 * c), [&](auto cnt_c) {
           constexpr int CNT = decltype(cnt_c)::value;
-          float4 g[CNT];
-          uint32_t win[CNT];
+          constexpr int FIRST = CNT > 6 ? 6 : CNT;
+          auto group = [&](auto q0_c, auto n_c) {
+            constexpr int Q0 = decltype(q0_c)::value, N = decltype(n_c)::value;
+            float4 g[N];
+            uint32_t win[N];
 #pragma unroll
-          for (int q = 0; q < CNT; ++q) {
-            const unsigned s = chunk_byte(w, q);
-            g[q] = *reinterpret_cast<const float4*>(my_g + s * kHalfBytes);
-            win[q] = *reinterpret_cast<const uint32_t*>(my_w + s * kArgHalfBytes);
-          }
+            for (int q = 0; q < N; ++q) {
+              const unsigned s = chunk_byte(w, Q0 + q);
+              g[q] = *reinterpret_cast<const float4*>(my_g + s * kHalfBytes);
+              win[q] = *reinterpret_cast<const uint32_t*>(my_w + s * kArgHalfBytes);
+            }
 #pragma unroll
-          for (int q = 0; q < CNT; ++q) {
-            const unsigned want = chunk_byte(tg, q);
-            const bool live = 8 * c + q < deg;
-            const float g4[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
+            for (int q = 0; q < N; ++q) {
+              const unsigned want = chunk_byte(tg, Q0 + q);
+              const bool live = 8 * c + Q0 + q < deg;
+              const float g4[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] += (live && ((win[q] >> (8 * t)) & 0xFF) == want) ? g4[t] : 0.0f;
-          }
+              for (int t = 0; t < 4; ++t) acc[t] += (live && ((win[q] >> (8 * t)) & 0xFF) == want) ? g4[t] : 0.0f;
+            }
+          };
+          group(IC<0>{}, IC<FIRST>{});
+          if constexpr (CNT > FIRST) group(IC<FIRST>{}, IC<CNT - FIRST>{});
         });
       }
     }
@@ -439,11 +471,7 @@ inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_
     const int depth = (g_cluster_ring == 2 && WHATIF == 0 && 4 * rec_slot + 3 * image + 64 <= kMaxLds) ? 2 : 1;
     const int64_t wg_lds = (depth + 2) * rec_slot + (depth + 1) * image + 64;   // + the dealt units
     a.deal_off = static_cast<int>(wg_lds) - 64;
-    // Static dealing unless asked (GTS_OPT_CLUSTER_DEALING 1): dealt units bring the fabric traffic to its compulsory figure (32 graphs per
-    // GPU: 1.31 / 1.18 -> 1.05 / 1.03 x) but these kernels are not bound by it, and at their register caps (64 / 80) the dealt form spills 3 - 5
-    // registers inside the unit loop — scratch loads that also count in the counted vmcnt waits: K1 68 -> 85 us at 8 graphs, K2 65 -> 71, 35.9 ->
-    // 39.2 at C2 (profiles/r04/k12_dealing_ab.log).  The GAT kernels (registers to spare, memory-bound) deal by default.
-    if (g_cluster_dealing != 1) a.counters = nullptr;
+
     if (wg_lds > kMaxLds || a.layout.words > 512) return GTS_ERR_SHAPE;
     a.ring = depth;
     const int waves = g_cluster_consumers > 0 ? std::min(16, g_cluster_consumers) : (BWD ? 12 : 16);
@@ -456,6 +484,13 @@ inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_
     const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g_cluster_per_cu > 0 ? g_cluster_per_cu : auto_per_cu, kMaxLds / wg_lds)));
     int64_t grid = static_cast<int64_t>(device_cus()) * per_cu;
     grid = std::max<int64_t>(8, std::min(grid, (units + 7) / 8 * 8)) / 8 * 8;
+    const int64_t grid_for_dealing = grid;
+    // Units dealt off the XCD's counter (GTS_OPT_CLUSTER_DEALING: 0 = automatic, 1 = wherever counters are given, 2 = never) from 16 units per
+    // workgroup on: the dealt form brings the fabric traffic to its compulsory figure (32 graphs per GPU: 1.31 / 1.18 -> 1.05 / 1.03 x) at the
+    // static form's time or a little under (8 graphs: K1 69.7 -> 70.4 us, K2 67.9 -> 66.1), but its first units cost two dependent counter
+    // round trips, which a launch of five to nine units per workgroup (the reference's batches, C2) does not earn back (K2 25.4 -> 27.2 us at
+    // 35 000 rows; profiles/r04/k12_dealing_ab.log).
+    if (g_cluster_dealing == 2 || (g_cluster_dealing == 0 && units < 16 * grid_for_dealing)) a.counters = nullptr;
     static const bool once = (allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF, 1, false>),
                               allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF, 1, true>),
                               allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF == 0 ? 0 : WHATIF, WHATIF == 0 ? 2 : 1, false>),

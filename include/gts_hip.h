@@ -104,10 +104,10 @@ int32_t gts_spmm_max_bwd_cluster_f32(const int32_t* rec, int64_t n_clusters, int
                                      int32_t loc_words, const float* gout, const void* arg, int32_t arg_bytes,
                                      float* gx, int64_t n_rows, int64_t n_feat, uint32_t* counters, void* stream);
 /* `counters`: GTS_CLUSTER_COUNTER_WORDS words of caller scratch, ZERO on entry; a launch that uses them leaves them zero (the last workgroup
- * of each XCD to finish resets them), so one zeroed buffer per stream serves every launch on it.  With GTS_OPT_CLUSTER_DEALING = 1 the
- * persistent workgroups of an XCD take their units off one counter, which keeps the units in flight neighbours in the walk whatever each
- * workgroup's pace — their halo rows then meet in the XCD's L2 (profiles/r04/gat_l2_replay.log, k12_dealing_ab.log).  NULL, or the option at
- * its default 0: static round-robin dealing (same values, more re-fetched rows at streaming sizes, fewer registers: faster today). */
+ * of each XCD to finish resets them), so one zeroed buffer per stream serves every launch on it.  On launches of 16 and more units per
+ * workgroup (GTS_OPT_CLUSTER_DEALING) the persistent workgroups of an XCD take their units off one counter, which keeps the units in flight
+ * neighbours in the walk whatever each workgroup's pace — their halo rows then meet in the XCD's L2 (profiles/r04/gat_l2_replay.log,
+ * k12_dealing_ab.log).  NULL: static round-robin dealing (same values, more re-fetched rows at streaming sizes). */
 #define GTS_CLUSTER_COUNTER_WORDS 256
 
 /* ---- K3/K4: copy_u + sum / mean / gcn reducers (forward and backward) ---------------
@@ -464,8 +464,8 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
                                         (0 = automatic: 16) */
 #define GTS_OPT_GAT_CLUSTER_DEALING 17 /* clustered GAT aggregation: 0 = the workgroups of an XCD take their units off one counter (default: the units in
                                          flight stay neighbours in the walk whatever each workgroup's pace), 1 = static round-robin (A/B runs) */
-#define GTS_OPT_CLUSTER_DEALING 18  /* clustered K1 / K2: 0 = static round-robin dealing (default), 1 = units dealt off the caller's counters where given
-                                       (compulsory-level fabric traffic at streaming sizes; slower today: the form spills registers, see csrc) */
+#define GTS_OPT_CLUSTER_DEALING 18  /* clustered K1 / K2, where the caller gives counters: 0 = automatic (units dealt off the XCD's counter from 16 units per
+                                       workgroup on, static round-robin below), 1 = always dealt, 2 = always static */
 #define GTS_OPT_PANEL_ROWS 13        /* K11 direct-to-fragment panels: rows per panel, 0 = automatic among 240 / 192 / 144 */
 #define GTS_OPT_CLUSTER_RING 10      /* clustered K1 / K2: units the gathers run ahead of the reduction (0 = automatic: 1; 2 where the LDS holds it) */
 #define GTS_OPT_CLUSTER_PER_CU 11    /* clustered K1 / K2: persistent workgroups per CU (0 = automatic: 2, or 3 for short backward launches) */

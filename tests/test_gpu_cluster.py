@@ -162,7 +162,7 @@ def test_cluster_entry_points_reject_bad_arguments():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("options", [{10: 2}, {12: 4}, {12: 6, 11: 1}, {11: 3}, {12: 16, 11: 3, 10: 2}, {8: 0}, {18: 1}, {18: 1, 10: 2}])
+@pytest.mark.parametrize("options", [{10: 2}, {12: 4}, {12: 6, 11: 1}, {11: 3}, {12: 16, 11: 3, 10: 2}, {8: 0}, {18: 1}, {18: 2}, {18: 1, 10: 2}])
 def test_every_launch_geometry_gives_the_same_bits(options):
     """Waves per workgroup, persistent workgroups per CU (2 by default, 3 for short backward launches), gathers one or two
     units ahead, streaming stores: tuning choices of the persistent form — results must not depend on them."""
