@@ -27,7 +27,10 @@ def _check(got, want64, bound64):
 
 SHAPES = [(1, 4, 4), (37, 4, 8), (128, 256, 4), (129, 4, 256), (300, 256, 256), (1000, 20, 256),
           (515, 256, 260), (64, 8, 4), (2049, 128, 64), (250, 300, 132), (60000, 4, 4), (59999, 8, 8),
-          (60000, 256, 4), (59999, 260, 8), (5, 64, 4), (4097, 1024, 8), (60000, 4, 256)]
+          (60000, 256, 4), (59999, 260, 8), (5, 64, 4), (4097, 1024, 8), (60000, 4, 256),
+          # the reference's own first layer (in_feats 20, utils/hyperparam_helpers.py:22) at its batch size: fc_pool 20 -> 20 (one lane per
+          # row), g @ W_neigh 256 -> 20 and a 256 -> 20 forward (rows streamed, two per wave), 20 -> 256
+          (34992, 20, 20), (34992, 20, 256), (34992, 256, 20), (33, 20, 20), (7, 256, 20)]
 
 
 @pytest.mark.parametrize("m,k,n", SHAPES)
