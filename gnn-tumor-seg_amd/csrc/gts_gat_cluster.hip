@@ -576,8 +576,9 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
   for (int q = 0; q < HIST; ++q) g_hist[q] = s_hist[q] = r_hist[q] = 0;
   if (dynamic) {                               // the first PIPE units of this workgroup in one add: PIPE - 1 for the prologue, one for iteration 0
     if (wave == n_waves - 1) {
-      publish(take(PIPE - 1), PIPE - 1, 0);
-      publish(take(1), 1, 6);
+      const unsigned first = take(PIPE);      // ONE round trip for the prologue's units and the one iteration 0 enters
+      publish(first, PIPE - 1, 0);
+      publish(first + (PIPE - 1), 1, 6);
     }
     barrier_all();
   }

@@ -361,8 +361,9 @@ __global__ __launch_bounds__(1024, BWD ? 6 : 8) void spmm_cluster_stream_kernel(
   // the gathers of unit `it`).
   if constexpr (dynamic) {
     if (wave == n_waves - 1) {
-      publish(take(PIPE - 1), PIPE - 1, 0);   // the prologue's units ...
-      publish(take(1), 1, 6);                 // ... and the one iteration 0 enters
+      const unsigned first = take(PIPE);      // ONE round trip for the prologue's units and the one iteration 0 enters
+      publish(first, PIPE - 1, 0);
+      publish(first + (PIPE - 1), 1, 6);
     }
     barrier_all();
   }
@@ -458,6 +459,38 @@ inline LdsPlan lds_plan(int max_rows, int max_srcs, int loc_words, bool bwd) {
   return p;
 }
 
+// launch geometry of the streaming form (shared with gts_cluster_uses_counters): LDS per workgroup, gather depth, persistent workgroups
+struct ClusterGeometry {
+  int64_t wg_lds, grid;
+  int depth, waves;
+  bool deals;      // units dealt off the XCD's counter (where the caller gives counters)
+};
+inline ClusterGeometry cluster_geometry(int64_t n_clusters, int words, int slot_bytes, int image_off, bool bwd, bool whatif) {
+  ClusterGeometry g;
+  const int64_t units = 2LL * n_clusters;
+  // depth + 2 record slots + depth + 1 images per workgroup; two workgroups per CU.  Gathers run one unit ahead; two units ahead
+  // (GTS_OPT_CLUSTER_RING = 2, where that fits) is kept for A/B runs: no gain measured
+  const int64_t rec_slot = 1024LL * ((words + 255) / 256), image = slot_bytes - image_off;
+  g.depth = (g_cluster_ring == 2 && !whatif && 4 * rec_slot + 3 * image + 64 <= kMaxLds) ? 2 : 1;
+  g.wg_lds = (g.depth + 2) * rec_slot + (g.depth + 1) * image + 64;   // + the dealt units
+  g.waves = g_cluster_consumers > 0 ? std::min(16, g_cluster_consumers) : (bwd ? 12 : 16);
+  // persistent workgroups per CU: two; three (where the LDS holds them) for a backward launch that gives a workgroup only a
+  // few units — C2: 8.8 units per workgroup, the reference's batches: 5 — where the pipeline's fill and drain weigh most
+  // (profiles/r04/tune_k2_small.log, operands from HBM: 37.0 -> 35.2 us at 60 000 rows, 22.8 -> 22.0 at 35 000; nothing either way from
+  // 120 000 rows on, and nothing in the training step, where the gradient rows were just written by the GEMM in front: 36.7 / 36.9 us)
+  const int auto_per_cu = (bwd && units <= 24LL * device_cus()) ? 3 : 2;
+  const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g_cluster_per_cu > 0 ? g_cluster_per_cu : auto_per_cu, kMaxLds / std::max<int64_t>(1, g.wg_lds))));
+  g.grid = static_cast<int64_t>(device_cus()) * per_cu;
+  g.grid = std::max<int64_t>(8, std::min(g.grid, (units + 7) / 8 * 8)) / 8 * 8;
+  // Units dealt off the XCD's counter (GTS_OPT_CLUSTER_DEALING: 0 = automatic, 1 = wherever counters are given, 2 = never) from 16 units per
+  // workgroup on: the dealt form brings the fabric traffic to its compulsory figure (32 graphs per GPU: 1.31 / 1.18 -> 1.05 / 1.03 x) at the
+  // static form's time or a little under (8 graphs: K1 69.7 -> 70.4 us, K2 67.9 -> 66.1), but its first units cost a counter round trip
+  // before anything else starts, which a launch of five to nine units per workgroup (the reference's batches, C2) does not earn back
+  // (K2 25.4 -> 27.2 us at 35 000 rows; profiles/r04/k12_dealing_ab.log).
+  g.deals = g_cluster_dealing == 1 || (g_cluster_dealing == 0 && units >= 16 * g.grid);
+  return g;
+}
+
 template <bool BWD, int ARGB, int WHATIF = 0>
 inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_t st) {
   const LdsPlan p = lds_plan(max_rows, a.max_srcs, loc_words, BWD);
@@ -465,32 +498,14 @@ inline int launch_cluster(ClusterArgs a, int max_rows, int loc_words, hipStream_
   if (p.slot_bytes > kMaxLds) return GTS_ERR_SHAPE;
   const int64_t units = 2LL * a.n_clusters;
   {
-    // the persistent streaming form: depth + 2 record slots + depth + 1 images per workgroup; two workgroups per CU.  Gathers run one
-    // unit ahead; two units ahead (GTS_OPT_CLUSTER_RING = 2, where that fits) is kept for A/B runs: no gain measured
-    const int64_t rec_slot = 1024LL * ((a.layout.words + 255) / 256), image = p.slot_bytes - p.image_off;
-    const int depth = (g_cluster_ring == 2 && WHATIF == 0 && 4 * rec_slot + 3 * image + 64 <= kMaxLds) ? 2 : 1;
-    const int64_t wg_lds = (depth + 2) * rec_slot + (depth + 1) * image + 64;   // + the dealt units
+    const ClusterGeometry geo = cluster_geometry(a.n_clusters, a.layout.words, p.slot_bytes, p.image_off, BWD, WHATIF != 0);
+    const int depth = geo.depth, waves = geo.waves;
+    const int64_t wg_lds = geo.wg_lds, grid = geo.grid;
     a.deal_off = static_cast<int>(wg_lds) - 64;
-
     if (wg_lds > kMaxLds || a.layout.words > 512) return GTS_ERR_SHAPE;
     a.ring = depth;
-    const int waves = g_cluster_consumers > 0 ? std::min(16, g_cluster_consumers) : (BWD ? 12 : 16);
     if (a.max_srcs > 64 * waves) return GTS_ERR_SHAPE;
-    // persistent workgroups per CU: two; three (where the LDS holds them) for a backward launch that gives a workgroup only a
-    // few units — C2: 8.8 units per workgroup, the reference's batches: 5 — where the pipeline's fill and drain weigh most
-    // (profiles/r04/tune_k2_small.log, operands from HBM: 37.0 -> 35.2 us at 60 000 rows, 22.8 -> 22.0 at 35 000; nothing either way from
-    // 120 000 rows on, and nothing in the training step, where the gradient rows were just written by the GEMM in front: 36.7 / 36.9 us)
-    const int auto_per_cu = (BWD && units <= 24LL * device_cus()) ? 3 : 2;
-    const int per_cu = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g_cluster_per_cu > 0 ? g_cluster_per_cu : auto_per_cu, kMaxLds / wg_lds)));
-    int64_t grid = static_cast<int64_t>(device_cus()) * per_cu;
-    grid = std::max<int64_t>(8, std::min(grid, (units + 7) / 8 * 8)) / 8 * 8;
-    const int64_t grid_for_dealing = grid;
-    // Units dealt off the XCD's counter (GTS_OPT_CLUSTER_DEALING: 0 = automatic, 1 = wherever counters are given, 2 = never) from 16 units per
-    // workgroup on: the dealt form brings the fabric traffic to its compulsory figure (32 graphs per GPU: 1.31 / 1.18 -> 1.05 / 1.03 x) at the
-    // static form's time or a little under (8 graphs: K1 69.7 -> 70.4 us, K2 67.9 -> 66.1), but its first units cost two dependent counter
-    // round trips, which a launch of five to nine units per workgroup (the reference's batches, C2) does not earn back (K2 25.4 -> 27.2 us at
-    // 35 000 rows; profiles/r04/k12_dealing_ab.log).
-    if (g_cluster_dealing == 2 || (g_cluster_dealing == 0 && units < 16 * grid_for_dealing)) a.counters = nullptr;
+    if (!geo.deals) a.counters = nullptr;
     static const bool once = (allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF, 1, false>),
                               allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF, 1, true>),
                               allow_big_lds(spmm_cluster_stream_kernel<BWD, ARGB, WHATIF == 0 ? 0 : WHATIF, WHATIF == 0 ? 2 : 1, false>),
@@ -685,6 +700,13 @@ inline bool bad_cluster_shape(int64_t n_clusters, int32_t max_rows, int32_t max_
   return gts::rec_layout(max_rows, max_srcs, loc_words, tag).words > 64 * gts::kRecRegs;
 }
 }  // namespace
+
+extern "C" int32_t gts_cluster_uses_counters(int64_t n_clusters, int32_t max_rows, int32_t max_srcs, int32_t loc_words, int32_t backward) {
+  using namespace gts;
+  if (n_clusters <= 0 || max_rows < 1 || max_srcs < 1 || loc_words < 0) return 0;
+  const LdsPlan p = lds_plan(max_rows, max_srcs, loc_words, backward != 0);
+  return cluster_geometry(n_clusters, rec_layout(max_rows, max_srcs, loc_words, backward != 0).words, p.slot_bytes, p.image_off, backward != 0, false).deals ? 1 : 0;
+}
 
 extern "C" int32_t gts_spmm_max_fwd_cluster_f32(const int32_t* rec, int64_t n_clusters, int32_t max_rows, int32_t max_srcs,
                                                 int32_t loc_words, const float* x, float* out, void* arg,

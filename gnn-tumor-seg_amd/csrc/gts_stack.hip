@@ -172,7 +172,7 @@ extern "C" int32_t gts_sage_pool_stack_fwd_f32(const int32_t* indptr, const int3
   char* base = static_cast<char*>(arena);
   auto f32 = [&](int64_t off) { return reinterpret_cast<float*>(base + off); };
   uint32_t* counters = nullptr;   // unit counters of the clustered K1 launches: zeroed once here, every launch leaves them zero
-  if (sched_rec != nullptr) {
+  if (sched_rec != nullptr && gts_cluster_uses_counters(sched_clusters, sched_rows, sched_srcs, sched_loc_words, 0) != 0) {
     counters = reinterpret_cast<uint32_t*>(base + plan.counters);
     if (hipMemsetAsync(counters, 0, 4 * GTS_CLUSTER_COUNTER_WORDS, static_cast<hipStream_t>(stream)) != hipSuccess) return GTS_ERR_SHAPE;
   }
@@ -278,7 +278,7 @@ extern "C" int32_t gts_sage_pool_stack_bwd_f32(const int32_t* t_indptr, const in
   char* base = static_cast<char*>(scratch);
   auto f32 = [&](int64_t off) { return reinterpret_cast<float*>(base + off); };
   uint32_t* counters = nullptr;   // unit counters of the clustered K2 launches (as in the forward call)
-  if (sched_rec != nullptr) {
+  if (sched_rec != nullptr && gts_cluster_uses_counters(sched_clusters, sched_rows, sched_srcs, sched_loc_words, 1) != 0) {
     counters = reinterpret_cast<uint32_t*>(base + plan.counters);
     if (hipMemsetAsync(counters, 0, 4 * GTS_CLUSTER_COUNTER_WORDS, static_cast<hipStream_t>(stream)) != hipSuccess) return GTS_ERR_SHAPE;
   }

@@ -28,6 +28,7 @@ SIGNATURES = {
     "gts_cluster_record_words": [_i32, _i32, _i32, _i32],
     "gts_cluster_schedule": [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p],
     "gts_cluster_lds_bytes": [_i32, _i32, _i32, _i32],
+    "gts_cluster_uses_counters": [_i64, _i32, _i32, _i32, _i32],
     "gts_spmm_max_fwd_cluster_f32": [_p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _i32, _i64, _i64, _p, _p],
     "gts_spmm_max_bwd_cluster_f32": [_p, _i64, _i32, _i32, _i32, _p, _p, _i32, _p, _i64, _i64, _p, _p],
     "gts_spmm_sum_f32": [_p, _p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _p],

@@ -109,6 +109,9 @@ int32_t gts_spmm_max_bwd_cluster_f32(const int32_t* rec, int64_t n_clusters, int
  * neighbours in the walk whatever each workgroup's pace — their halo rows then meet in the XCD's L2 (profiles/r04/gat_l2_replay.log,
  * k12_dealing_ab.log).  NULL: static round-robin dealing (same values, more re-fetched rows at streaming sizes). */
 #define GTS_CLUSTER_COUNTER_WORDS 256
+/* 1 when a launch over these records would deal its units off `counters` (so that a caller who carves them out of a scratch block knows whether
+ * they need zeroing at all), 0 when it deals statically */
+int32_t gts_cluster_uses_counters(int64_t n_clusters, int32_t max_rows, int32_t max_srcs, int32_t loc_words, int32_t backward);
 
 /* ---- K3/K4: copy_u + sum / mean / gcn reducers (forward and backward) ---------------
  * Replaces DGL update_all(copy_u, sum|mean) of SAGEConv('mean'|'gcn')
