@@ -463,8 +463,8 @@ int32_t gts_weighted_ce_f32(const float* logits, const int64_t* labels, const fl
 #define GTS_OPT_CLUSTER_STREAMING 8 /* clustered K1 / K2: bit 0 = non-temporal stores of out / gx; -1 = per-kernel default */
 #define GTS_OPT_GAT_WALK 14          /* K5-K8: 1 = walk the (node, head) rows head-major (default), 0 = node-major */
 #define GTS_OPT_GAT_CLUSTER_WAVES 15 /* clustered GAT aggregation: waves per persistent workgroup (0 = default 12; up to 16) */
-#define GTS_OPT_GAT_CLUSTER_GROUP 16 /* clustered GAT aggregation: clusters of an XCD's span walked together through all their (head, half) slices
-                                        (0 = automatic: 16) */
+#define GTS_OPT_GAT_CLUSTER_GROUP 16 /* clustered GAT aggregation UNDER STATIC DEALING (option 17 = 1): clusters of an XCD's span walked together through
+                                        all their (head, half) slices (0 = 16; 100000 = the whole span).  Dealt units walk the whole span slice by slice */
 #define GTS_OPT_GAT_CLUSTER_DEALING 17 /* clustered GAT aggregation: 0 = the workgroups of an XCD take their units off one counter (default: the units in
                                          flight stay neighbours in the walk whatever each workgroup's pace), 1 = static round-robin (A/B runs) */
 #define GTS_OPT_CLUSTER_DEALING 18  /* clustered K1 / K2, where the caller gives counters: 0 = automatic (units dealt off the XCD's counter from 16 units per
