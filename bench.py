@@ -426,8 +426,8 @@ def main():
     if rank == 0:
         arg_b = batches[0][0].arg_bytes
         # the committed profiles ran the lattice workload at 4, 8 and 32 graphs per GPU (C2 / C3 models)
-        tag = {4: "", 8: "b8_", 32: "b32_"}.get(args.graphs_per_gpu)
-        profiled = tag is not None and args.graph_kind == "lattice" and args.config in ("c2", "c3", "c4", "c5")
+        tag = "real_" if args.config == "real" else {4: "", 8: "b8_", 32: "b32_"}.get(args.graphs_per_gpu)
+        profiled = tag is not None and args.graph_kind == "lattice" and args.config in ("c2", "c3", "c4", "c5", "real")
 
         def from_profile(fname, key):
             path = os.path.join(REPO, "profiles", fname)

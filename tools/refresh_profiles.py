@@ -57,7 +57,7 @@ c2 = stats("prof", f"{rnd}_bench", 65, f"Round {rnd[1:]}: bench.py --steps 20 --
 c3 = stats("prof_c3", f"{rnd}_bench_c3", 12, f"Round {rnd[1:]}: bench.py --config c3 --steps 5 --warmup 2 --blocks 1 (GAT 4x4x256; 2 + 5 + 5 = 12 steps)")
 b8 = stats("prof_b8", f"{rnd}_bench_c2_b8", 12, f"Round {rnd[1:]}: bench.py --config c4 --steps 5 --warmup 2 --blocks 1 (8 graphs per GPU; 2 + 5 + 5 = 12 steps)")
 b32 = stats("prof_b32", f"{rnd}_bench_c2_b32", 7, f"Round {rnd[1:]}: bench.py --graphs-per-gpu 32 --steps 3 --warmup 1 --blocks 1 (1 + 3 + 3 = 7 steps)")
-stats("prof_real", f"{rnd}_bench_real", 105, f"Round {rnd[1:]}: bench.py --config real --steps 20 --warmup 5 --blocks 1 (5 + 20 + 20 fresh-batch steps + 3 x 20 resident)")
+real = stats("prof_real", f"{rnd}_bench_real", 105, f"Round {rnd[1:]}: bench.py --config real --steps 20 --warmup 5 --blocks 1 (5 + 20 + 20 fresh-batch steps + 3 x 20 resident)")
 stats("prof_aux", f"{rnd}_aux", 1, f"Round {rnd[1:]}: tools/measure_aux_kernels.py (streaming kernels around the network)")
 K1 = (("spmm_cluster_stream_kernel<false, 1",), ("spmm_max_fwd_kernel<4, 64, 1>",))     # clustered form first, plain form otherwise
 K2 = (("spmm_cluster_stream_kernel<true, 1",), ("spmm_max_bwd_kernel<4, 64, 1>",))
@@ -78,12 +78,14 @@ avg = {"source": f"{dst}/{rnd}_bench_kernel_stats.csv (rocprofv3 --kernel-trace 
        "gemm_panel_direct_avg_us": panel, "gemm_panel_direct_calls": panel_calls,
        "gemm_wgrad_256x256_avg_us": mean_us(c2, ("wgrad_stream_kernel",) if any("wgrad_stream_kernel" in n for n in c2)
                                              else ("gemm_kernel<256, 256, 4, 4, false, false, true",))[0]}
-for tag, rows, label in (("", c2, "C2"), ("b8_", b8, "--config c4 (8 graphs per GPU)"), ("b32_", b32, "--graphs-per-gpu 32")):
+for tag, rows, label in (("", c2, "C2"), ("b8_", b8, "--config c4 (8 graphs per GPU)"), ("b32_", b32, "--graphs-per-gpu 32"),
+                         ("real_", real, "--config real (6 graphs of 5 832 nodes, in_feats 20)")):
     for key, needles in (("spmm_max_fwd_f256", K1), ("spmm_max_bwd_f256", K2)):
         us, calls, form = first_mean(rows, needles)
         avg[f"{tag}{key}_avg_us"], avg[f"{tag}{key}_form"] = us, form
     if tag:
-        avg[f"{tag}source"] = f"{dst}/{rnd}_bench_c2_{tag[:-1]}_kernel_stats.csv ({label})"
+        stem = "real" if tag == "real_" else f"c2_{tag[:-1]}"
+        avg[f"{tag}source"] = f"{dst}/{rnd}_bench_{stem}_kernel_stats.csv ({label})"
 avg["c3_source"] = f"{dst}/{rnd}_bench_c3_kernel_stats.csv (--config c3)"
 # hidden-layer launches only (D = 256); the clustered form of a call = its weight pass + the streaming kernel
 for key, plain, clustered in (("gat_fwd", "gat_fwd_kernel<4, 64>", ("gat_cluster_stream_kernel<0,", "gat_weights_one_chunk_kernel<false>")),
