@@ -505,7 +505,7 @@ __global__ __launch_bounds__(1024, MINW) void gat_cluster_stream_kernel(const Ga
     for (int q = 0; q < count; ++q) {
       const unsigned idx = base + q;
       const bool ok = idx < static_cast<unsigned long long>(n_local);
-      const unsigned sl = idx / static_cast<unsigned>(span);        // the whole span slice by slice
+      const unsigned sl = idx / static_cast<unsigned>(max(span, 1));   // the whole span slice by slice (an empty span deals nothing)
       if (lane == 0) {
         l_deal[2 * (slot0 + q)] = ok ? clo + static_cast<int>(idx - sl * static_cast<unsigned>(span)) : -1;
         l_deal[2 * (slot0 + q) + 1] = ok ? static_cast<int>(sl) : 0;
